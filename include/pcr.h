@@ -1,0 +1,186 @@
+/*
+ * pcr.h -- C ABI of the MI355X-native point-cloud registration hot path.
+ *
+ * One shared library (libpcr.so, hipcc --offload-arch=gfx950) exports exactly
+ * these symbols.  Plain C: opaque handles, caller-owned host buffers, integer
+ * status codes, no exceptions across the boundary.  Every entry point names
+ * the reference interface (file:line under /root/reference) it stands in for.
+ *
+ * Threading: a pcr_ctx owns one device and one HIP stream and is not
+ * thread-safe; distinct contexts are independent.  Host arrays are only read
+ * (or written) during the call.
+ *
+ * Arithmetic: the whole path computes in IEEE binary64 like the reference
+ * (Open3D points are double; NumPy float64), with FMA contraction disabled in
+ * device code so squared distances are bit-identical to
+ * (dx*dx + dy*dy) + dz*dz evaluated on the host.
+ */
+#ifndef PCR_H
+#define PCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCR_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- status */
+enum {
+    PCR_OK = 0,
+    /* soft status: result is valid.  Registration/main.py:125-127 prints
+     * "ICP failed, cannot find enough associations!" and returns the current
+     * transformation; so do we. */
+    PCR_E_TOO_FEW_ASSOC = 1,
+    PCR_E_INVALID = -1,     /* bad argument                                  */
+    PCR_E_EMPTY = -2,       /* empty cloud (reference: IndexError/ValueError) */
+    PCR_E_NOMEM = -3,
+    PCR_E_HIP = -4,         /* HIP runtime error; see pcr_last_error()        */
+    PCR_E_NO_DEVICE = -5,
+    PCR_E_UNSUPPORTED = -6,
+    PCR_E_TOO_MANY_ITERS = -7
+};
+
+typedef struct pcr_ctx pcr_ctx;
+typedef struct pcr_cloud pcr_cloud;
+typedef struct pcr_index pcr_index;
+
+PCR_API const char* pcr_strerror(int status);
+PCR_API const char* pcr_last_error(const pcr_ctx* ctx); /* last HIP error text */
+PCR_API const char* pcr_version(void);
+
+/* --------------------------------------------------------------- context */
+PCR_API int pcr_ctx_create(int device, pcr_ctx** out);
+PCR_API int pcr_ctx_destroy(pcr_ctx* ctx);
+PCR_API int pcr_ctx_sync(pcr_ctx* ctx);
+/* device facts for the bench: name (<=255 chars), CU count, HBM bytes */
+PCR_API int pcr_ctx_device_info(pcr_ctx* ctx, char* name256, int* cu_count, int64_t* hbm_bytes);
+
+/* ---------------------------------------------------------------- clouds
+ * Device-resident (n,3) float64 cloud stored as 32-byte records {x,y,z,id}.
+ * Stands in for o3d.geometry.PointCloud.points (Registration/main.py:52-56)
+ * and the (N,3) ndarrays of Kdtree_Octree/lesson2 and voxel_filter.py:19.
+ * float32 input (the .bin readers, main.py:10-17) is widened exactly.       */
+PCR_API int pcr_cloud_upload_f32(pcr_ctx* ctx, const float* xyz, int64_t n, int64_t stride_floats, pcr_cloud** out);
+PCR_API int pcr_cloud_upload_f64(pcr_ctx* ctx, const double* xyz, int64_t n, int64_t stride_doubles, pcr_cloud** out);
+PCR_API int pcr_cloud_download_f64(pcr_ctx* ctx, const pcr_cloud* cloud, double* xyz_out /* n*3 */);
+PCR_API int64_t pcr_cloud_size(const pcr_cloud* cloud);
+PCR_API int pcr_cloud_free(pcr_ctx* ctx, pcr_cloud* cloud);
+/* PointCloud.transform(T) in place (Registration/main.py:110), T row-major 4x4 */
+PCR_API int pcr_cloud_transform(pcr_ctx* ctx, pcr_cloud* cloud, const double T[16]);
+
+/* ----------------------------------------------------------- target index
+ * Stands in for o3d.geometry.KDTreeFlann(target) (Registration/main.py:105)
+ * and kdtree_construction / octree_construction
+ * (Kdtree_Octree/lesson2/kdtree.py:119-137, octree.py:310-328).             */
+enum { PCR_INDEX_GRID = 0, PCR_INDEX_BRUTE = 1 };
+/* cell <= 0: choose the finest cell size from the cloud's extent and size */
+PCR_API int pcr_index_build(pcr_ctx* ctx, const pcr_cloud* target, int kind, double cell, pcr_index** out);
+PCR_API int pcr_index_free(pcr_ctx* ctx, pcr_index* index);
+PCR_API int pcr_index_kind(const pcr_index* index);
+PCR_API double pcr_index_cell(const pcr_index* index);
+PCR_API int64_t pcr_index_size(const pcr_index* index);
+
+/* Exact 1-NN of every query point (optionally transformed by T first) in the
+ * indexed cloud: the body of the association loop Registration/main.py:116-121
+ * == find_associations, icp_template.py:113-126.  idx_out[i] = target index or
+ * -1 when the nearest neighbour is not closer than max_d2 (strict <, on the
+ * SQUARED distance like main.py:119); max_d2 <= 0 or +inf disables the gate.
+ * d2_out[i] = exact squared distance (binary64) of the reported neighbour.   */
+PCR_API int pcr_nn1(pcr_ctx* ctx, const pcr_index* index, const pcr_cloud* queries, const double* T /* 16 or NULL */,
+                    double max_d2, int32_t* idx_out, double* d2_out);
+
+/* Batched k-NN / radius queries: kdtree_knn_search / octree_knn_search
+ * (kdtree.py:141-172, octree.py:262-306) and *_radius_search
+ * (kdtree.py:176-208, octree.py:166-259), Q queries per call.
+ * knn: idx/dist are (Q,k), ascending distance, EUCLIDEAN (not squared) like
+ * result_set.py; unfilled slots (k > n) hold index 0 / distance 1e10 like
+ * KNNResultSet.__init__ (result_set.py:19-22).
+ * radius: two-pass.  Call with idx == NULL to get counts[Q] (neighbours with
+ * distance <= r, inclusive like result_set.py:80); then with offsets[Q+1]
+ * (exclusive prefix sums of counts) to fill idx/dist, ascending distance.    */
+PCR_API int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries_xyz, int64_t q, int k,
+                    int32_t* idx_out, double* dist_out);
+PCR_API int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries_xyz, int64_t q, double radius,
+                       int64_t* counts_out, const int64_t* offsets, int32_t* idx_out, double* dist_out);
+
+/* -------------------------------------------------------------------- ICP */
+enum { PCR_ICP_COMPAT_MAIN = 0, /* Registration/main.py:97-156 semantics, returns LAST increment */
+       PCR_ICP_TOTAL = 1        /* icp_template.py:128-200 semantics, returns composed transform */ };
+enum { PCR_RMETRIC_FROBENIUS = 0, PCR_RMETRIC_GEODESIC = 1 };
+#define PCR_ICP_MAX_LOG 256
+
+typedef struct pcr_icp_params {
+    int32_t max_iter;   /* main.py:98  -> 100 */
+    double r_thres;     /* main.py:101 -> 0.5 */
+    double t_thres;     /* main.py:102 -> 0.5 */
+    double max_d2;      /* main.py:103 -> 5 (threshold on SQUARED distance) */
+    int32_t mode;       /* PCR_ICP_COMPAT_MAIN | PCR_ICP_TOTAL */
+    int32_t r_metric;   /* PCR_RMETRIC_* (template hint icp_template.py:184) */
+    int32_t min_iter;   /* bench only: never break before this many iterations (0 = reference behaviour) */
+    int32_t reserved;
+} pcr_icp_params;
+
+typedef struct pcr_icp_result {
+    double T[16];          /* row-major 4x4: last increment (COMPAT) or composed (TOTAL) */
+    double T_total[16];    /* composed transform in both modes                          */
+    int32_t iters;         /* Procrustes solves performed                               */
+    int32_t status;        /* PCR_OK or PCR_E_TOO_FEW_ASSOC                             */
+    int64_t n_assoc;       /* associations of the last solved iteration                 */
+    double cost;           /* ||B - (R A + t)||_F of the last solve (main.py:141)       */
+    double mean_d2;        /* mean squared NN distance of the last association pass     */
+    double r_diff[PCR_ICP_MAX_LOG]; /* log["R_diff"], icp_template.py:189 */
+    double t_diff[PCR_ICP_MAX_LOG]; /* log["t_diff"], icp_template.py:190 */
+    double device_ms;      /* HIP-event time of the whole loop on the ctx stream        */
+    double nn_kernel_ms;   /* sum of HIP-event times of the correspondence kernel       */
+    int32_t nn_launches;   /* launches of the correspondence kernel                     */
+    int32_t reserved;
+} pcr_icp_result;
+
+PCR_API void pcr_icp_default_params(pcr_icp_params* p);
+/* icp_point2point(source, target, transformation) (main.py:97) / ICP (icp_template.py:128).
+ * `source` is updated in place exactly like main.py:110 mutates it (COMPAT) or
+ * icp_template.py:195-196 (TOTAL).                                            */
+PCR_API int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* target_index, const pcr_icp_params* params,
+                    const double T0[16], pcr_icp_result* result);
+
+/* One association + accumulation pass (no solve): the 18 moments the Procrustes
+ * step needs: {K, Sa[3], Sb[3], Sba[9] (row-major b_i*a_j), Saa, Sbb}, taken about
+ * `origin_out[3]`.  Lets tests check the fused kernel against the oracle.      */
+PCR_API int pcr_icp_moments(pcr_ctx* ctx, const pcr_cloud* source, const pcr_index* target_index, const double* T,
+                            double max_d2, double moments_out[18], double origin_out[3], double* sum_d2_out);
+/* procrustes_transformation(A, B) (icp_template.py:43-54, main.py:131-141) on host
+ * arrays A,B laid out (3,K) row-major; R_out[9], t_out[3].                     */
+PCR_API int pcr_procrustes(const double* A, const double* B, int64_t k, double R_out[9], double t_out[3], double* cost_out);
+/* rotmat2quaternion / homo2tq (main.py:158-174): out = tx,ty,tz,qw,qx,qy,qz */
+PCR_API int pcr_homo2tq(const double T[16], double out7[7]);
+
+/* ----------------------------------------------------------- voxel filter
+ * voxel_filter(point_cloud, leaf_size, type) (Pca_and_Voxel_filter/voxel_filter.py:10-68).
+ * pcr_voxel_keys: per-point key h (float64, bit-exact, voxel_filter.py:20-33) and D[3].
+ * pcr_voxel_filter: mode 0 = "centroid", 1 = "random" (explicit seed).  Output
+ * rows = occupied voxels - 1 (the reference never emits its last group,
+ * voxel_filter.py:42-51); out must hold n*3 doubles.                         */
+PCR_API int pcr_voxel_keys(pcr_ctx* ctx, const double* xyz, int64_t n, double leaf, double* h_out, double D_out[3]);
+PCR_API int pcr_voxel_filter(pcr_ctx* ctx, const double* xyz, int64_t n, double leaf, int mode, uint64_t seed,
+                             double* out_xyz, int64_t* n_out);
+/* device-resident variant used by the downsample -> ICP pipeline (config 3) */
+PCR_API int pcr_voxel_filter_cloud(pcr_ctx* ctx, const pcr_cloud* in, double leaf, int mode, uint64_t seed, pcr_cloud** out);
+
+/* --------------------------------------------------------------------- ISS
+ * Keypoint_detection_ISS/ISS.py:35-73.  lambdas_out (n,3) descending eigenvalues
+ * of the weighted scatter; counts_out[n] = |N(p_i)| (inclusive radius, self
+ * included).  keypoints_out holds up to max_keypoints indices after NMS.     */
+PCR_API int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, double gamma21, double gamma32, double nms_radius,
+                    int max_keypoints, double* lambdas_out, int32_t* counts_out, int32_t* keypoints_out, int* n_keypoints_out);
+
+/* ------------------------------------------------------------- timing aid
+ * HIP-event stopwatch on the ctx stream, for bench.py's roofline figures.   */
+PCR_API int pcr_timer_start(pcr_ctx* ctx);
+PCR_API int pcr_timer_stop_ms(pcr_ctx* ctx, double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCR_H */

@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- golden-vector generator.  Runs ONLY in the build container.
+
+Imports the reference's own functions from /root/reference (read-only, never
+copied) and records their outputs on seeded synthetic inputs as small .npz
+fixtures under tests/golden/.  The GPU box has no /root/reference; tests there
+read only the committed fixtures.
+
+What is imported, and how:
+  * Kdtree_Octree/lesson2/{kdtree,octree,result_set}.py  -- pure NumPy, as is.
+  * Pca_and_Voxel_filter/voxel_filter.py:voxel_filter     -- needs only empty
+    stand-in modules for its unused top-of-file imports (open3d, pyntcloud).
+  * Registration/main.py:icp_point2point, rotmat2quaternion, homo2tq -- the
+    reference calls Open3D (absent here, version unpinned) for exactly three
+    things: PointCloud.points, PointCloud.transform(T) in place, and
+    KDTreeFlann.search_knn_vector_3d(q, 1) -> exact 1-NN with SQUARED distance.
+    A 20-line stand-in provides those (float64, scipy cKDTree = exact NN); the
+    loop, gating, Procrustes, convergence test and return value that get
+    recorded are the reference's own code.
+  * Keypoint_detection_ISS/ISS.py has no functions (script body) and cannot be
+    imported; ISS parity is "unpinned by the reference" (DESIGN.md).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/ref_harness.py [--big]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import importlib.util
+import io
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _load_synthetic():
+    spec = importlib.util.spec_from_file_location(
+        "pcp_synthetic", os.path.join(ROOT, "point-cloud-process_amd", "synthetic.py")
+    )
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# --------------------------------------------------------------------------
+# stand-ins for the absent third-party modules
+# --------------------------------------------------------------------------
+class _PointCloud:
+    def __init__(self, pts=None):
+        self.points = None if pts is None else np.array(pts, dtype=np.float64)
+
+    def transform(self, T):
+        T = np.asarray(T, dtype=np.float64)
+        self.points = self.points @ T[:3, :3].T + T[:3, 3]
+        return self
+
+    def __deepcopy__(self, memo):
+        return _PointCloud(self.points)
+
+
+class _KDTreeFlann:
+    def __init__(self, pc):
+        from scipy.spatial import cKDTree
+
+        self._tree = cKDTree(np.asarray(pc.points, dtype=np.float64))
+
+    def search_knn_vector_3d(self, q, k):
+        q = np.asarray(q, dtype=np.float64).reshape(3)
+        d, i = self._tree.query(q, k=k)
+        d = np.atleast_1d(d)
+        i = np.atleast_1d(i)
+        return [k, i.tolist(), (d * d).tolist()]
+
+
+def install_stubs():
+    o3d = types.ModuleType("open3d")
+    geom = types.ModuleType("open3d.geometry")
+    geom.PointCloud = _PointCloud
+    geom.KDTreeFlann = _KDTreeFlann
+    o3d.geometry = geom
+    sys.modules["open3d"] = o3d
+    sys.modules["open3d.geometry"] = geom
+    pynt = types.ModuleType("pyntcloud")
+    pynt.PyntCloud = object
+    sys.modules["pyntcloud"] = pynt
+    if "tqdm" not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except Exception:  # pragma: no cover
+            t = types.ModuleType("tqdm")
+            t.tqdm = lambda x, *a, **k: x
+            sys.modules["tqdm"] = t
+
+
+def import_ref(subdir, name):
+    path = os.path.join(REF, subdir)
+    if path not in sys.path:
+        sys.path.insert(0, path)
+    spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(path, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# --------------------------------------------------------------------------
+# G1: voxel filter
+# --------------------------------------------------------------------------
+def gen_voxel(syn):
+    ref = import_ref("Pca_and_Voxel_filter", "voxel_filter")
+    out = {}
+    cases = []
+    rng = np.random.default_rng(11)
+    clouds = {
+        "uni1000": rng.uniform(-1.0, 1.0, (1000, 3)),
+        "obj2048": syn.object_cloud(2048, seed=3).astype(np.float64),
+        "kitti20k": syn.kitti_like_scan(20000, seed=5).astype(np.float64),
+        "thin500": np.c_[rng.uniform(0, 3, 500), rng.uniform(0, 0.04, 500), rng.uniform(0, 2, 500)],
+        "exactmult": np.c_[np.linspace(0.0, 2.0, 201), np.linspace(0.0, 1.0, 201), np.zeros(201)],
+    }
+    leafs = {"uni1000": [0.05, 0.1, 0.2], "obj2048": [0.05, 0.1], "kitti20k": [0.2, 0.5], "thin500": [0.1], "exactmult": [0.1]}
+    for cname, pts in clouds.items():
+        out[f"{cname}_in"] = pts
+        for leaf in leafs[cname]:
+            tag = f"{cname}_leaf{leaf}"
+            cen = ref.voxel_filter(pts, leaf, "centroid")
+            # per-point key h exactly as voxel_filter.py:20-33 computes it (float64)
+            mx = np.max(pts, axis=0)
+            mn = np.min(pts, axis=0)
+            D = (mx - mn) // leaf
+            h = np.empty(len(pts))
+            for i in range(len(pts)):
+                p = pts[i, :][:, np.newaxis]
+                hx = np.floor((p[0] - mn[0]) / leaf)
+                hy = np.floor((p[1] - mn[1]) / leaf)
+                hz = np.floor((p[2] - mn[2]) / leaf)
+                h[i] = (hx + hy * D[0] + hz * D[0] * D[1])[0]
+            import random as _r
+
+            _r.seed(1234)
+            rnd = ref.voxel_filter(pts, leaf, "random")
+            out[f"{tag}_centroid"] = np.asarray(cen, dtype=np.float64).reshape(-1, 3)
+            out[f"{tag}_random"] = np.asarray(rnd, dtype=np.float64).reshape(-1, 3)
+            out[f"{tag}_h"] = h
+            out[f"{tag}_D"] = np.asarray(D, dtype=np.float64)
+            cases.append(tag)
+            print("voxel", tag, "->", out[f"{tag}_centroid"].shape, "D", D)
+    # single-voxel cloud: the reference returns an empty array (drop-last quirk)
+    one = rng.uniform(0, 0.01, (50, 3))
+    r = ref.voxel_filter(one, 1.0, "centroid")
+    out["onevoxel_in"] = one
+    out["onevoxel_centroid_shape"] = np.asarray(np.asarray(r).shape, dtype=np.int64)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(GOLD, "voxel_filter.npz"), **out)
+
+
+# --------------------------------------------------------------------------
+# G2: kd-tree / octree / result sets
+# --------------------------------------------------------------------------
+def gen_nn_api(syn):
+    sys.path.insert(0, os.path.join(REF, "Kdtree_Octree", "lesson2"))
+    kd = import_ref(os.path.join("Kdtree_Octree", "lesson2"), "kdtree")
+    oc = import_ref(os.path.join("Kdtree_Octree", "lesson2"), "octree")
+    rs = importlib.import_module("result_set")
+    out = {}
+    rng = np.random.default_rng(21)
+    dbs = {"rand64": rng.random((64, 3)), "kitti4000": syn.kitti_like_scan(4000, seed=9).astype(np.float64)}
+    for name, db in dbs.items():
+        out[f"{name}_db"] = db
+        leaf = 4 if len(db) <= 64 else 32
+        kroot = kd.kdtree_construction(db, leaf_size=leaf)
+        oroot = oc.octree_construction(db, leaf, 0.0001)
+        nq = 6
+        queries = np.concatenate([db[rng.integers(0, len(db), 3)] + rng.normal(0, 0.01, (3, 3)), rng.uniform(db.min(0), db.max(0), (3, 3))])
+        out[f"{name}_queries"] = queries
+        for k in (1, 8):
+            for tree, fn, root in (("kd", kd.kdtree_knn_search, kroot), ("oct", oc.octree_knn_search, oroot)):
+                D = np.zeros((nq, k))
+                I = np.zeros((nq, k), dtype=np.int64)
+                C = np.zeros(nq, dtype=np.int64)
+                for qi, q in enumerate(queries):
+                    r = rs.KNNResultSet(capacity=k)
+                    fn(root, db, r, q)
+                    D[qi] = [x.distance for x in r.dist_index_list]
+                    I[qi] = [x.index for x in r.dist_index_list]
+                    C[qi] = r.comparison_counter
+                out[f"{name}_{tree}_knn{k}_dist"] = D
+                out[f"{name}_{tree}_knn{k}_idx"] = I
+                out[f"{name}_{tree}_knn{k}_cmp"] = C
+        for rad in (0.5, 1.0) if name != "rand64" else (0.25, 0.5):
+            for tree, fn, root in (
+                ("kd", kd.kdtree_radius_search, kroot),
+                ("oct", oc.octree_radius_search, oroot),
+                ("octfast", oc.octree_radius_search_fast, oroot),
+            ):
+                for qi, q in enumerate(queries):
+                    r = rs.RadiusNNResultSet(radius=rad)
+                    fn(root, db, r, q)
+                    lst = sorted(r.dist_index_list)
+                    out[f"{name}_{tree}_rad{rad}_q{qi}_dist"] = np.array([x.distance for x in lst])
+                    out[f"{name}_{tree}_rad{rad}_q{qi}_idx"] = np.array([x.index for x in lst], dtype=np.int64)
+                    out[f"{name}_{tree}_rad{rad}_q{qi}_count"] = np.array([r.count, r.comparison_counter], dtype=np.int64)
+    # KNNResultSet insertion semantics on a hand-made stream with ties and under-filled capacity
+    stream_d = np.array([0.5, 0.2, 0.5, 0.9, 0.2, 0.1, 0.5, 3.0])
+    stream_i = np.arange(100, 108)
+    for cap in (3, 12):
+        r = rs.KNNResultSet(capacity=cap)
+        for d, i in zip(stream_d, stream_i):
+            r.add_point(d, int(i))
+        out[f"stream_cap{cap}_dist"] = np.array([x.distance for x in r.dist_index_list])
+        out[f"stream_cap{cap}_idx"] = np.array([x.index for x in r.dist_index_list], dtype=np.int64)
+        out[f"stream_cap{cap}_meta"] = np.array([r.count, r.comparison_counter, float(r.worstDist())])
+    out["stream_d"] = stream_d
+    out["stream_i"] = stream_i
+    r = rs.RadiusNNResultSet(radius=0.5)
+    for d, i in zip(stream_d, stream_i):
+        r.add_point(d, int(i))
+    out["stream_radius_idx"] = np.array([x.index for x in r.dist_index_list], dtype=np.int64)
+    out["stream_radius_meta"] = np.array([r.count, r.comparison_counter, float(r.worstDist())])
+    np.savez_compressed(os.path.join(GOLD, "nn_api.npz"), **out)
+    print("nn_api: wrote", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------
+# G3/G4/G5: icp_point2point, pose utils, literal L-matrix Procrustes
+# --------------------------------------------------------------------------
+def _literal_procrustes(A, B):
+    """The reference's Procrustes lines run literally (Registration/main.py:133-141 are
+    inline in icp_point2point; this calls them through a tiny 1-iteration ICP is not possible,
+    so G5 re-executes those exact numpy expressions on (3,K) inputs)."""
+    N = A.shape[1]
+    L = np.identity(N) - 1.0 / N * np.ones((N, 1)) * np.ones((1, N))
+    Ap = np.matmul(A, L)
+    Bp = np.matmul(B, L)
+    mediate = np.matmul(Bp, Ap.T)
+    u, s, vt = np.linalg.svd(mediate)
+    R = np.matmul(u, vt)
+    t = 1.0 / N * np.matmul((B - np.matmul(R, A)), np.ones((N, 1)))
+    cost = np.linalg.norm(B - (np.matmul(R, A) + t * np.ones((1, N))))
+    return R, t, cost
+
+
+def gen_icp(syn, big=False):
+    install_stubs()
+    ref = import_ref("Registration", "main")
+    out = {}
+    cases = []
+
+    svd_calls = [0]
+    real_svd = np.linalg.svd
+
+    def counting_svd(*a, **k):
+        svd_calls[0] += 1
+        return real_svd(*a, **k)
+
+    def run(tag, src, tgt, T0):
+        S = _PointCloud(src)
+        Tg = _PointCloud(tgt)
+        svd_calls[0] = 0
+        np.linalg.svd = counting_svd
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                Tout = ref.icp_point2point(S, Tg, np.array(T0, dtype=np.float64))
+        finally:
+            np.linalg.svd = real_svd
+        out[f"{tag}_src"] = np.asarray(src)
+        out[f"{tag}_tgt"] = np.asarray(tgt)
+        out[f"{tag}_T0"] = np.asarray(T0, dtype=np.float64)
+        out[f"{tag}_T"] = np.asarray(Tout, dtype=np.float64)
+        out[f"{tag}_iters"] = np.array([svd_calls[0]], dtype=np.int64)
+        out[f"{tag}_src_after"] = np.asarray(S.points, dtype=np.float64)
+        out[f"{tag}_failed"] = np.array([int("ICP failed" in buf.getvalue())], dtype=np.int64)
+        cases.append(tag)
+        print("icp", tag, "iters", svd_calls[0], "failed", out[f"{tag}_failed"][0], "t", np.round(Tout[:3, 3], 4))
+
+    # C1-like: 2048-pt object vs rotated copy (+noise so the clouds are not permutations)
+    rng = np.random.default_rng(31)
+    obj = syn.object_cloud(2048, seed=1)
+    Trot = syn.rigid_transform((0, 0, 1), np.deg2rad(10.0), (0.02, -0.01, 0.03))
+    obj_src = ((obj.astype(np.float64) - Trot[:3, 3]) @ Trot[:3, :3] + rng.normal(0, 1e-3, obj.shape)).astype(np.float32)
+    run("obj2048_id", obj_src, obj, np.eye(4))
+    run("obj2048_near", obj_src, obj, syn.rigid_transform((0, 0, 1), np.deg2rad(9.0), (0.0, 0.0, 0.0)))
+
+    # KITTI-shaped pairs, small and larger perturbations, identity and big-rotation init
+    for n, seed in ((2048, 2), (4000, 3)):
+        src, tgt, Tt = syn.perturbed_pair(n, seed=seed)
+        run(f"kitti{n}_id", src, tgt, np.eye(4))
+        run(f"kitti{n}_truth", src, tgt, Tt)
+    src, tgt, Tt = syn.perturbed_pair(3000, seed=4, angle_deg=56.0, t=(1.5, -0.7, 0.1))
+    run("kitti3000_bigrot_id", src, tgt, np.eye(4))
+    run("kitti3000_bigrot_near", src, tgt, syn.rigid_transform((0.1, 0.2, 1.0), np.deg2rad(50.0), (1.0, -0.5, 0.0)))
+    # failure path: clouds 100 m apart -> < 3 associations
+    far = (src.astype(np.float64) + np.array([500.0, 0, 0])).astype(np.float32)
+    run("kitti3000_far_fail", far, tgt, np.eye(4))
+    # float64 inputs that are not float32-representable (voxel-filtered style)
+    rng = np.random.default_rng(33)
+    s64 = src[:1500].astype(np.float64) + rng.normal(0, 1e-3, (1500, 3))
+    t64 = tgt[:2500].astype(np.float64) + rng.normal(0, 1e-3, (2500, 3))
+    run("f64_1500", s64, t64, np.eye(4))
+    if big:
+        src, tgt, Tt = syn.perturbed_pair(20000, seed=6)
+        run("kitti20000_id", src, tgt, np.eye(4))
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(GOLD, "icp_compat.npz"), **out)
+
+    # G4 pose utils
+    pose = {}
+    rng = np.random.default_rng(41)
+    Rs = []
+    for i in range(64):
+        ax = rng.normal(size=3)
+        ang = rng.uniform(-np.pi, np.pi) if i % 4 else np.pi - 1e-3 * i
+        Rs.append(syn.rigid_transform(ax, ang, rng.uniform(-5, 5, 3)))
+    Rs = np.array(Rs)
+    tq = np.array([ref.homo2tq(T) for T in Rs], dtype=np.float64)
+    pose["T"] = Rs
+    pose["tq"] = tq
+    rows = np.zeros((len(Rs), 9))
+    rows[:, 0] = np.arange(len(Rs))
+    rows[:, 1] = np.arange(len(Rs)) + 100
+    rows[:, 2:] = tq
+    buf = io.StringIO()
+    np.savetxt(buf, rows, delimiter=",", header="idx1,idx2,t_x,t_y,t_z,q_w,q_x,q_y,q_z", fmt="%i,%i,%f,%f,%f,%f,%f,%f,%f")
+    pose["csv"] = np.array(buf.getvalue())
+    np.savez_compressed(os.path.join(GOLD, "pose_utils.npz"), **pose)
+
+    # G5 literal Procrustes
+    kab = {}
+    rng = np.random.default_rng(51)
+    for K in (3, 10, 500, 3000):
+        A = rng.normal(0, 10, (3, K))
+        Tt = syn.rigid_transform(rng.normal(size=3), rng.uniform(-1, 1), rng.uniform(-2, 2, 3))
+        B = Tt[:3, :3] @ A + Tt[:3, 3:4] + rng.normal(0, 0.05, (3, K))
+        R, t, cost = _literal_procrustes(A, B)
+        kab[f"K{K}_A"], kab[f"K{K}_B"] = A, B
+        kab[f"K{K}_R"], kab[f"K{K}_t"], kab[f"K{K}_cost"] = R, t, np.array([cost])
+    # reflection case (no det fix in the reference: R may have det -1)
+    A = rng.normal(0, 1, (3, 50))
+    B = A * np.array([[1.0], [1.0], [-1.0]]) + rng.normal(0, 1e-3, (3, 50))
+    R, t, cost = _literal_procrustes(A, B)
+    kab["refl_A"], kab["refl_B"], kab["refl_R"], kab["refl_t"], kab["refl_cost"] = A, B, R, t, np.array([cost])
+    np.savez_compressed(os.path.join(GOLD, "procrustes.npz"), **kab)
+    print("pose/procrustes goldens written")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true", help="also run the N=20000 literal ICP (~40 s, ~10 GB RSS)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present: goldens can only be regenerated in the build container")
+    os.makedirs(GOLD, exist_ok=True)
+    sys.dont_write_bytecode = True
+    syn = _load_synthetic()
+    install_stubs()
+    if a.only in ("", "voxel"):
+        gen_voxel(syn)
+    if a.only in ("", "nn"):
+        gen_nn_api(syn)
+    if a.only in ("", "icp"):
+        gen_icp(syn, big=a.big)
+
+
+if __name__ == "__main__":
+    main()

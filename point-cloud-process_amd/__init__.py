@@ -1,0 +1,30 @@
+"""MI355X-native registration hot path (ICP + nearest neighbour + voxel filter).
+
+Drop-in for the reference's Registration/main.py, Registration/icp_template.py,
+Kdtree_Octree/lesson2 and Pca_and_Voxel_filter/voxel_filter.py call surfaces,
+backed by hand-written HIP kernels for gfx950 behind the C ABI in include/pcr.h.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("point-cloud-process_amd")`` or through the
+top-level alias module ``pcp_amd``.
+"""
+from . import _lib  # noqa: F401
+from . import synthetic  # noqa: F401
+from .device import Context, DeviceCloud, TargetIndex, default_context, icp_device  # noqa: F401
+from .registration import (  # noqa: F401
+    ICP,
+    KDTreeFlann,
+    PointCloud,
+    copysign,
+    find_associations,
+    homo2tq,
+    icp_point2point,
+    procrustes_transformation,
+    read_bin_velodyne,
+    read_oxford_bin,
+    read_velodyne_bin,
+    rotmat2quaternion,
+    write_reg_result,
+)
+
+__version__ = "0.1.0"

@@ -1,0 +1,317 @@
+// Brute-force exact 1-NN as an MFMA-tiled contraction (config 2 of BASELINE.json).
+//
+// For target b and query a (both taken about the target's bbox centre o):
+//     |a-b|^2 = |a'|^2 + ( |b'|^2 - 2 b'.a' )          a' = a-o, b' = b-o
+// The bracket is a K=4 contraction  [-2b'x, -2b'y, -2b'z, |b'|^2] . [a'x, a'y, a'z, 1]
+// which is exactly one v_mfma_f64_16x16x4_f64 per 16 targets x 16 queries.
+// binary64 is used because the expanded form cancels: KITTI coordinates reach
+// 80 m (|b'|^2 ~ 6e3) while neighbour spacing is ~3 cm (d^2 ~ 1e-3); binary32
+// (ulp(6e3) = 5e-4) cannot rank neighbours there and gfx950 has no xf32.  In
+// binary64 the contraction ranks candidates to ~1e-12 m^2; the winner of every
+// lane's 4 accumulator rows is then re-evaluated in the direct form
+// (dx*dx+dy*dy)+dz*dz so the reported d^2 is bit-identical to the grid path.
+//
+// HBM layout: mfma_a[tile][64] doubles -- the A operand of tile `tile` in lane
+// order (lane l holds A[i = l&15][k = l>>4]) so one wave loads a tile with a
+// single coalesced 512-B read.  3.84 MB for 120k targets: L2/MALL resident and
+// streamed by every wave.
+#include <cfloat>
+#include <cmath>
+#include "pcr_internal.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int BR_NT = 4;          // query tiles (of 16) per wave -> 64 queries per wave
+constexpr int BR_WAVES = 4;       // waves per block
+constexpr int BR_QPB = BR_NT * 16 * BR_WAVES;  // queries per block = 256
+
+__global__ void brute_prep_kernel(const pcr_pt* __restrict__ pts, long long n, long long n_tiles, double ox, double oy, double oz,
+                                  double* __restrict__ mfma_a) {
+    long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_tiles * 64) return;
+    long long t = g >> 6;
+    int l = (int)(g & 63);
+    int i = l & 15, k = l >> 4;
+    long long j = t * 16 + i;
+    double v;
+    if (j < n) {
+        pcr_pt p = pts[j];
+        double bx = p.x - ox, by = p.y - oy, bz = p.z - oz;
+        v = (k == 0) ? -2.0 * bx : (k == 1) ? -2.0 * by : (k == 2) ? -2.0 * bz : ((bx * bx + by * by) + bz * bz);
+    } else {
+        v = (k == 3) ? 1e300 : 0.0;  // padding rows can never win
+    }
+    mfma_a[g] = v;
+}
+
+struct brute_cand {  // per (target split, query): best candidate of that split
+    double d2;
+    int id;
+    int pad;
+};
+
+__device__ static inline double dist2_pt(double ax, double ay, double az, const pcr_pt& b) {
+    double dx = ax - b.x, dy = ay - b.y, dz = az - b.z;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+__global__ void __launch_bounds__(256, 2)
+brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tgt, long long n_tgt, long long n_tiles, int n_splits,
+                const pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, double ox, double oy, double oz,
+                brute_cand* __restrict__ cand /* [n_splits][nq] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long qbase = (long long)blockIdx.x * BR_QPB + wave * (BR_NT * 16);
+    const int split = blockIdx.y;
+    // this lane's own query (one query per lane, 64 per wave)
+    const long long qi = qbase + lane;
+    double ax = 0, ay = 0, az = 0;
+    if (qi < nq) {
+        pcr_pt p = q[qi];
+        ax = p.x; ay = p.y; az = p.z;
+        if (has_x) {
+            double nx = ((x.r[0] * p.x + x.r[1] * p.y) + x.r[2] * p.z) + x.t[0];
+            double ny = ((x.r[3] * p.x + x.r[4] * p.y) + x.r[5] * p.z) + x.t[1];
+            double nz = ((x.r[6] * p.x + x.r[7] * p.y) + x.r[8] * p.z) + x.t[2];
+            ax = nx; ay = ny; az = nz;
+        }
+    }
+    // B operands: tile tt covers queries 16*tt .. 16*tt+15 of this wave; lane l supplies B[k = l>>4][j = l&15]
+    const int kk = lane >> 4, jj = lane & 15;
+    double bq[BR_NT];
+#pragma unroll
+    for (int tt = 0; tt < BR_NT; ++tt) {
+        int src = tt * 16 + jj;
+        double sx = __shfl(ax, src, 64) - ox, sy = __shfl(ay, src, 64) - oy, sz = __shfl(az, src, 64) - oz;
+        bq[tt] = (kk == 0) ? sx : (kk == 1) ? sy : (kk == 2) ? sz : 1.0;
+    }
+    double best[BR_NT];
+    int btile[BR_NT];
+#pragma unroll
+    for (int tt = 0; tt < BR_NT; ++tt) { best[tt] = DBL_MAX; btile[tt] = -1; }
+
+    const long long per = (n_tiles + n_splits - 1) / n_splits;
+    const long long t0 = (long long)split * per;
+    const long long t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+    if (t0 < t1) {
+        double a_cur = mfma_a[t0 * 64 + lane];
+        for (long long t = t0; t < t1; ++t) {
+            double a_nxt = (t + 1 < t1) ? mfma_a[(t + 1) * 64 + lane] : 0.0;
+#pragma unroll
+            for (int tt = 0; tt < BR_NT; ++tt) {
+                v4f64 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur, bq[tt], zero, 0, 0, 0);
+                double m = fmin(fmin(acc[0], acc[1]), fmin(acc[2], acc[3]));
+                if (m < best[tt]) { best[tt] = m; btile[tt] = (int)t; }
+            }
+            a_cur = a_nxt;
+        }
+    }
+    // exact re-evaluation of each lane's 4 candidate rows, then merge the 4 row groups of a query
+    const int rg = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < BR_NT; ++tt) {
+        int src = tt * 16 + jj;
+        double qx = __shfl(ax, src, 64), qy = __shfl(ay, src, 64), qz = __shfl(az, src, 64);
+        double bd2 = DBL_MAX;
+        int bid = 0x7fffffff;
+        if (btile[tt] >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                long long j = (long long)btile[tt] * 16 + rg + 4 * r;
+                if (j < n_tgt) {
+                    pcr_pt b = tgt[j];
+                    double d2 = dist2_pt(qx, qy, qz, b);
+                    if (d2 < bd2 || (d2 == bd2 && (int)j < bid)) { bd2 = d2; bid = (int)j; }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            double od2 = __shfl_xor(bd2, off, 64);
+            int oid = __shfl_xor(bid, off, 64);
+            if (od2 < bd2 || (od2 == bd2 && oid < bid)) { bd2 = od2; bid = oid; }
+        }
+        long long qo = qbase + tt * 16 + jj;
+        if (rg == 0 && qo < nq) {
+            brute_cand c;
+            c.d2 = bd2;
+            c.id = (bd2 == DBL_MAX) ? -1 : bid;
+            c.pad = 0;
+            cand[(long long)split * nq + qo] = c;
+        }
+    }
+}
+
+// merge the per-split candidates; MODE 0: write idx/d2 (nn1); MODE 1: fused ICP accumulate (+ in-place transform)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+brute_merge_kernel(const brute_cand* __restrict__ cand, int n_splits, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x,
+                   const pcr_pt* __restrict__ tgt, double max_d2, int gated, int write_back, double ox, double oy, double oz,
+                   int* __restrict__ idx_out, double* __restrict__ d2_out, double* __restrict__ partials) {
+    __shared__ double s_part[4][PCR_NMOM];
+    long long qi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double m[PCR_NMOM];
+#pragma unroll
+    for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+    if (qi < nq) {
+        double bd2 = DBL_MAX;
+        int bid = -1;
+        for (int s = 0; s < n_splits; ++s) {
+            brute_cand c = cand[(long long)s * nq + qi];
+            if (c.id >= 0 && (c.d2 < bd2 || (c.d2 == bd2 && c.id < bid))) { bd2 = c.d2; bid = c.id; }
+        }
+        if (bid >= 0 && gated && !(bd2 < max_d2)) bid = -1;
+        pcr_pt p = q[qi];
+        if (MODE == 0) {
+            idx_out[p.id] = bid;
+            d2_out[p.id] = (bd2 == DBL_MAX) ? INFINITY : bd2;
+        } else {
+            double ax = p.x, ay = p.y, az = p.z;
+            if (has_x) {
+                ax = ((x.r[0] * p.x + x.r[1] * p.y) + x.r[2] * p.z) + x.t[0];
+                ay = ((x.r[3] * p.x + x.r[4] * p.y) + x.r[5] * p.z) + x.t[1];
+                az = ((x.r[6] * p.x + x.r[7] * p.y) + x.r[8] * p.z) + x.t[2];
+            }
+            if (write_back) {
+                p.x = ax; p.y = ay; p.z = az;
+                q[qi] = p;
+            }
+            if (bid >= 0) {
+                pcr_pt b = tgt[bid];
+                double a0 = ax - ox, a1 = ay - oy, a2 = az - oz;
+                double b0 = b.x - ox, b1 = b.y - oy, b2 = b.z - oz;
+                m[0] = 1.0;
+                m[1] = a0; m[2] = a1; m[3] = a2;
+                m[4] = b0; m[5] = b1; m[6] = b2;
+                m[7] = b0 * a0; m[8] = b0 * a1; m[9] = b0 * a2;
+                m[10] = b1 * a0; m[11] = b1 * a1; m[12] = b1 * a2;
+                m[13] = b2 * a0; m[14] = b2 * a1; m[15] = b2 * a2;
+                m[16] = (a0 * a0 + a1 * a1) + a2 * a2;
+                m[17] = (b0 * b0 + b1 * b1) + b2 * b2;
+                m[18] = bd2;
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < PCR_NMOM - 1; ++k) {
+            double v = m[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            m[k] = v;
+        }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < PCR_NMOM; ++k) s_part[wave][k] = m[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < PCR_NMOM) {
+            double v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+            partials[(long long)blockIdx.x * PCR_NMOM + threadIdx.x] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) brute_reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
+                                                                     double* __restrict__ out) {
+    __shared__ double s[32][32];
+    const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double v = 0.0;
+    if (k < PCR_NMOM) {
+        for (int b = slice; b < nblocks; b += 32) v += partials[(long long)b * PCR_NMOM + k];
+    }
+    s[slice][k] = v;
+    __syncthreads();
+    for (int st = 16; st > 0; st >>= 1) {
+        if (slice < st) s[slice][k] += s[slice + st][k];
+        __syncthreads();
+    }
+    if (slice == 0 && k < PCR_NMOM) out[k] = s[0][k];
+}
+
+// ------------------------------------------------------------------- host
+int pcr_brute_build(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_index* idx) {
+    const long long n = tgt->n;
+    idx->n_tiles = (n + 15) / 16;
+    int rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 64 * idx->n_tiles, (void**)&idx->mfma_a))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&idx->plain))) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(idx->plain, tgt->d, sizeof(pcr_pt) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    const long long threads = idx->n_tiles * 64;
+    hipLaunchKernelGGL(brute_prep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)idx->plain, n,
+                       (long long)idx->n_tiles, idx->view.origin[0], idx->view.origin[1], idx->view.origin[2], idx->mfma_a);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+void pcr_brute_free(pcr_ctx* ctx, pcr_index* idx) {
+    pcr_dev_free(ctx, idx->mfma_a, sizeof(double) * 64 * idx->n_tiles);
+    pcr_dev_free(ctx, idx->plain, sizeof(pcr_pt) * idx->n);
+    idx->mfma_a = nullptr;
+    idx->plain = nullptr;
+}
+
+static int brute_splits(pcr_ctx* ctx, long long nq, long long n_tiles) {
+    long long qblocks = (nq + BR_QPB - 1) / BR_QPB;
+    long long want = 8ll * ctx->cu_count;  // >= 8 blocks of 4 waves per CU in the grid
+    long long s = (want + qblocks - 1) / qblocks;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    if (s > n_tiles) s = n_tiles;
+    return (int)s;
+}
+
+static int brute_search(pcr_ctx* ctx, const pcr_index* idx, const pcr_pt* q, int64_t nq, const pcr_xform* x, brute_cand** cand_out,
+                        int* splits_out) {
+    const int splits = brute_splits(ctx, nq, idx->n_tiles);
+    brute_cand* cand = nullptr;
+    int rc = pcr_dev_alloc(ctx, sizeof(brute_cand) * (size_t)splits * nq, (void**)&cand);
+    if (rc) return rc;
+    pcr_xform xi;
+    pcr_xform_from_T(nullptr, &xi);
+    dim3 grid((unsigned)((nq + BR_QPB - 1) / BR_QPB), (unsigned)splits);
+    hipLaunchKernelGGL(brute_nn_kernel, grid, dim3(256), 0, ctx->stream, (const double*)idx->mfma_a, (const pcr_pt*)idx->plain,
+                       (long long)idx->n, (long long)idx->n_tiles, splits, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
+                       idx->view.origin[0], idx->view.origin[1], idx->view.origin[2], cand);
+    PCR_HIP(ctx, hipGetLastError());
+    *cand_out = cand;
+    *splits_out = splits;
+    return PCR_OK;
+}
+
+int pcr_brute_nn1(pcr_ctx* ctx, const pcr_index* idx, const pcr_pt* q, int64_t nq, const pcr_xform* x, double max_d2,
+                  int32_t* d_idx, double* d_d2) {
+    const bool gated = (max_d2 > 0) && std::isfinite(max_d2);
+    brute_cand* cand;
+    int splits;
+    int rc = brute_search(ctx, idx, q, nq, x, &cand, &splits);
+    if (rc) return rc;
+    pcr_xform xi;
+    pcr_xform_from_T(nullptr, &xi);
+    const int grid = (int)((nq + 255) / 256);
+    hipLaunchKernelGGL(brute_merge_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, (const brute_cand*)cand, splits, (pcr_pt*)q,
+                       (long long)nq, x ? *x : xi, x ? 1 : 0, (const pcr_pt*)idx->plain, max_d2, gated ? 1 : 0, 0,
+                       idx->view.origin[0], idx->view.origin[1], idx->view.origin[2], d_idx, d_d2, (double*)nullptr);
+    PCR_HIP(ctx, hipGetLastError());
+    pcr_dev_free(ctx, cand, sizeof(brute_cand) * (size_t)splits * nq);
+    return PCR_OK;
+}
+
+int pcr_brute_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, const pcr_xform* x, double max_d2, int write_back,
+                       double* d_moments) {
+    const bool gated = (max_d2 > 0) && std::isfinite(max_d2);
+    brute_cand* cand;
+    int splits;
+    int rc = brute_search(ctx, idx, q, nq, x, &cand, &splits);
+    if (rc) return rc;
+    const int grid = (int)((nq + 255) / 256);
+    if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid))) return rc;
+    hipLaunchKernelGGL(brute_merge_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, (const brute_cand*)cand, splits, q, (long long)nq, *x,
+                       1, (const pcr_pt*)idx->plain, max_d2, gated ? 1 : 0, write_back, idx->view.origin[0], idx->view.origin[1],
+                       idx->view.origin[2], (int*)nullptr, (double*)nullptr, ctx->d_partials);
+    hipLaunchKernelGGL(brute_reduce_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ctx->d_partials, grid, d_moments);
+    PCR_HIP(ctx, hipGetLastError());
+    pcr_dev_free(ctx, cand, sizeof(brute_cand) * (size_t)splits * nq);
+    return PCR_OK;
+}

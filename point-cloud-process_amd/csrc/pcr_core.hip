@@ -1,0 +1,290 @@
+// Context, device memory, cloud upload/download/transform, timers.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include "pcr_internal.h"
+
+extern "C" {
+
+const char* pcr_version(void) { return "pcr 0.1 (gfx950, f64)"; }
+
+const char* pcr_strerror(int s) {
+    switch (s) {
+        case PCR_OK: return "ok";
+        case PCR_E_TOO_FEW_ASSOC: return "ICP failed, cannot find enough associations!";
+        case PCR_E_INVALID: return "invalid argument";
+        case PCR_E_EMPTY: return "empty point cloud";
+        case PCR_E_NOMEM: return "out of memory";
+        case PCR_E_HIP: return "HIP runtime error";
+        case PCR_E_NO_DEVICE: return "no HIP device (libpcr.so needs an AMD GPU; there is no CPU fallback)";
+        case PCR_E_UNSUPPORTED: return "unsupported";
+        case PCR_E_TOO_MANY_ITERS: return "max_iter exceeds PCR_ICP_MAX_LOG";
+        default: return "unknown status";
+    }
+}
+
+const char* pcr_last_error(const pcr_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int pcr_ctx_create(int device, pcr_ctx** out) {
+    if (!out) return PCR_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PCR_E_NO_DEVICE;
+    if (device < 0 || device >= count) return PCR_E_INVALID;
+    pcr_ctx* c = new pcr_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return PCR_E_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->cu_count = prop.multiProcessorCount;
+        snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+        c->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PCR_E_HIP; }
+    hipEventCreate(&c->ev0);
+    hipEventCreate(&c->ev1);
+    hipEventCreate(&c->ev2);
+    hipEventCreate(&c->ev3);
+    c->h_pinned_bytes = 4096;
+    if (hipHostMalloc((void**)&c->h_pinned, c->h_pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return PCR_E_NOMEM;
+    }
+    if (hipMalloc((void**)&c->d_counters, 4096) != hipSuccess) { delete c; return PCR_E_NOMEM; }
+    hipMemsetAsync(c->d_counters, 0, 4096, c->stream);
+    *out = c;
+    return PCR_OK;
+}
+
+int pcr_ctx_destroy(pcr_ctx* c) {
+    if (!c) return PCR_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& b : c->free_list) hipFree(b.p);
+    if (c->d_partials) hipFree(c->d_partials);
+    if (c->d_counters) hipFree(c->d_counters);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    hipEventDestroy(c->ev0);
+    hipEventDestroy(c->ev1);
+    hipEventDestroy(c->ev2);
+    hipEventDestroy(c->ev3);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return PCR_OK;
+}
+
+int pcr_ctx_sync(pcr_ctx* c) {
+    if (!c) return PCR_E_INVALID;
+    PCR_HIP(c, hipStreamSynchronize(c->stream));
+    return PCR_OK;
+}
+
+int pcr_ctx_device_info(pcr_ctx* c, char* name256, int* cu, int64_t* hbm) {
+    if (!c) return PCR_E_INVALID;
+    if (name256) { strncpy(name256, c->name, 255); name256[255] = 0; }
+    if (cu) *cu = c->cu_count;
+    if (hbm) *hbm = c->hbm_bytes;
+    return PCR_OK;
+}
+
+int pcr_timer_start(pcr_ctx* c) {
+    if (!c) return PCR_E_INVALID;
+    PCR_HIP(c, hipEventRecord(c->ev2, c->stream));
+    return PCR_OK;
+}
+
+int pcr_timer_stop_ms(pcr_ctx* c, double* ms) {
+    if (!c || !ms) return PCR_E_INVALID;
+    PCR_HIP(c, hipEventRecord(c->ev3, c->stream));
+    PCR_HIP(c, hipEventSynchronize(c->ev3));
+    float f = 0;
+    PCR_HIP(c, hipEventElapsedTime(&f, c->ev2, c->ev3));
+    *ms = f;
+    return PCR_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ memory
+int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~size_t(255);
+    int best = -1;
+    for (int i = 0; i < (int)ctx->free_list.size(); ++i) {
+        size_t sz = ctx->free_list[i].sz;
+        if (sz >= bytes && sz <= 2 * bytes + 4096 && (best < 0 || sz < ctx->free_list[best].sz)) best = i;
+    }
+    if (best >= 0) {
+        *out = ctx->free_list[best].p;
+        ctx->free_list.erase(ctx->free_list.begin() + best);
+        return PCR_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto& b : ctx->free_list) hipFree(b.p);
+        ctx->free_list.clear();
+        e = hipMalloc(out, bytes);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+            return PCR_E_NOMEM;
+        }
+    }
+    return PCR_OK;
+}
+
+void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes) {
+    if (!p) return;
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~size_t(255);
+    // frees are stream-ordered with later allocations because every user of the
+    // block runs on ctx->stream
+    if (ctx->free_list.size() >= 64) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(ctx->free_list.front().p);
+        ctx->free_list.erase(ctx->free_list.begin());
+    }
+    ctx->free_list.push_back({p, bytes});
+}
+
+int pcr_ensure_scratch(pcr_ctx* ctx, size_t partial_bytes) {
+    if (ctx->d_partials_bytes >= partial_bytes) return PCR_OK;
+    if (ctx->d_partials) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(ctx->d_partials);
+        ctx->d_partials = nullptr;
+        ctx->d_partials_bytes = 0;
+    }
+    size_t want = partial_bytes < (1u << 20) ? (1u << 20) : partial_bytes;
+    PCR_HIP(ctx, hipMalloc((void**)&ctx->d_partials, want));
+    ctx->d_partials_bytes = want;
+    return PCR_OK;
+}
+
+void pcr_xform_from_T(const double* T, pcr_xform* x) {
+    if (!T) {
+        for (int i = 0; i < 9; ++i) x->r[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        x->t[0] = x->t[1] = x->t[2] = 0.0;
+        return;
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) x->r[3 * i + j] = T[4 * i + j];
+        x->t[i] = T[4 * i + 3];
+    }
+}
+
+// ------------------------------------------------------------------ clouds
+template <typename S>
+__global__ void expand_cloud_kernel(const S* __restrict__ in, long long n, long long stride, pcr_pt* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const S* p = in + i * stride;
+    pcr_pt o;
+    o.x = (double)p[0];
+    o.y = (double)p[1];
+    o.z = (double)p[2];
+    o.id = i;
+    out[i] = o;
+}
+
+__global__ void pack_xyz_kernel(const pcr_pt* __restrict__ in, long long n, double* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pcr_pt p = in[i];
+    out[3 * i + 0] = p.x;
+    out[3 * i + 1] = p.y;
+    out[3 * i + 2] = p.z;
+}
+
+// p' = R p + t, evaluated as ((r0*x + r1*y) + r2*z) + t with no FMA contraction.
+__global__ void transform_cloud_kernel(pcr_pt* __restrict__ pts, long long n, pcr_xform x) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pcr_pt p = pts[i];
+    double nx = ((x.r[0] * p.x + x.r[1] * p.y) + x.r[2] * p.z) + x.t[0];
+    double ny = ((x.r[3] * p.x + x.r[4] * p.y) + x.r[5] * p.z) + x.t[1];
+    double nz = ((x.r[6] * p.x + x.r[7] * p.y) + x.r[8] * p.z) + x.t[2];
+    p.x = nx;
+    p.y = ny;
+    p.z = nz;
+    pts[i] = p;
+}
+
+template <typename S>
+static int upload_impl(pcr_ctx* ctx, const S* xyz, int64_t n, int64_t stride, pcr_cloud** out) {
+    if (!ctx || !out) return PCR_E_INVALID;
+    *out = nullptr;
+    if (n < 0 || stride < 3 || (n > 0 && !xyz)) return PCR_E_INVALID;
+    if (n == 0) return PCR_E_EMPTY;
+    if (n > 0x7fffffffll) return PCR_E_UNSUPPORTED;
+    hipSetDevice(ctx->device);
+    pcr_cloud* c = new pcr_cloud();
+    c->n = n;
+    int rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&c->d);
+    if (rc != PCR_OK) { delete c; return rc; }
+    size_t raw_elems = (size_t)(n - 1) * stride + 3;
+    void* d_raw = nullptr;
+    rc = pcr_dev_alloc(ctx, raw_elems * sizeof(S), &d_raw);
+    if (rc != PCR_OK) { pcr_dev_free(ctx, c->d, sizeof(pcr_pt) * n); delete c; return rc; }
+    PCR_HIP(ctx, hipMemcpyAsync(d_raw, xyz, raw_elems * sizeof(S), hipMemcpyHostToDevice, ctx->stream));
+    int block = 256;
+    int grid = (int)((n + block - 1) / block);
+    hipLaunchKernelGGL(expand_cloud_kernel<S>, dim3(grid), dim3(block), 0, ctx->stream, (const S*)d_raw, (long long)n,
+                       (long long)stride, c->d);
+    PCR_HIP(ctx, hipGetLastError());
+    // the host buffer is caller-owned: finish reading it before returning
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pcr_dev_free(ctx, d_raw, raw_elems * sizeof(S));
+    *out = c;
+    return PCR_OK;
+}
+
+extern "C" {
+
+int pcr_cloud_upload_f32(pcr_ctx* ctx, const float* xyz, int64_t n, int64_t stride, pcr_cloud** out) {
+    return upload_impl<float>(ctx, xyz, n, stride, out);
+}
+
+int pcr_cloud_upload_f64(pcr_ctx* ctx, const double* xyz, int64_t n, int64_t stride, pcr_cloud** out) {
+    return upload_impl<double>(ctx, xyz, n, stride, out);
+}
+
+int pcr_cloud_download_f64(pcr_ctx* ctx, const pcr_cloud* c, double* out) {
+    if (!ctx || !c || !out) return PCR_E_INVALID;
+    hipSetDevice(ctx->device);
+    double* d_tmp = nullptr;
+    int rc = pcr_dev_alloc(ctx, sizeof(double) * 3 * c->n, (void**)&d_tmp);
+    if (rc != PCR_OK) return rc;
+    int block = 256;
+    int grid = (int)((c->n + block - 1) / block);
+    hipLaunchKernelGGL(pack_xyz_kernel, dim3(grid), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, (long long)c->n, d_tmp);
+    PCR_HIP(ctx, hipGetLastError());
+    PCR_HIP(ctx, hipMemcpyAsync(out, d_tmp, sizeof(double) * 3 * c->n, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pcr_dev_free(ctx, d_tmp, sizeof(double) * 3 * c->n);
+    return PCR_OK;
+}
+
+int64_t pcr_cloud_size(const pcr_cloud* c) { return c ? c->n : 0; }
+
+int pcr_cloud_free(pcr_ctx* ctx, pcr_cloud* c) {
+    if (!c) return PCR_OK;
+    if (!ctx) return PCR_E_INVALID;
+    pcr_dev_free(ctx, c->d, sizeof(pcr_pt) * c->n);
+    delete c;
+    return PCR_OK;
+}
+
+int pcr_cloud_transform(pcr_ctx* ctx, pcr_cloud* c, const double T[16]) {
+    if (!ctx || !c || !T) return PCR_E_INVALID;
+    hipSetDevice(ctx->device);
+    pcr_xform x;
+    pcr_xform_from_T(T, &x);
+    int block = 256;
+    int grid = (int)((c->n + block - 1) / block);
+    hipLaunchKernelGGL(transform_cloud_kernel, dim3(grid), dim3(block), 0, ctx->stream, c->d, (long long)c->n, x);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// Internal types shared by the host C++ and the HIP kernels of libpcr.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "pcr.h"
+
+#define PCR_HIDDEN __attribute__((visibility("hidden")))
+
+// 32-byte point record: x,y,z (binary64) + original index (int64 bits).
+struct __attribute__((aligned(32))) pcr_pt {
+    double x, y, z;
+    long long id;
+};
+
+struct pcr_xform {  // row-major 3x4: p' = R p + t
+    double r[9];
+    double t[3];
+};
+
+constexpr int PCR_MAX_LEVELS = 12;
+constexpr int PCR_COORD_BITS = 21;
+constexpr long long PCR_COORD_BIAS = 1ll << 20;  // multiple of 4^10: keeps level nesting aligned
+constexpr long long PCR_COORD_MAX = (1ll << PCR_COORD_BITS) - 1;
+constexpr unsigned long long PCR_EMPTY_KEY = ~0ull;
+
+struct pcr_cell_slot {  // 16 B open-addressing slot: Morton key of a cell -> [start,end) in the sorted cloud
+    unsigned long long key;
+    unsigned int start;
+    unsigned int end;
+};
+
+// Device view of the multi-level voxel-hash grid over one target cloud.
+struct pcr_grid_view {
+    const pcr_pt* pts;  // target points sorted by level-0 Morton key (id = original index)
+    long long n;
+    int levels;
+    double lo[3];    // grid origin (min corner of the target)
+    double cell0;    // level-0 cell size; level l has cell0 * 4^l
+    double inv_cell0;
+    const pcr_cell_slot* table[PCR_MAX_LEVELS];
+    unsigned int mask[PCR_MAX_LEVELS];  // capacity-1 (power of two)
+    double origin[3];                   // shift origin for moment accumulation (bbox centre)
+};
+
+struct pcr_cloud {
+    pcr_pt* d = nullptr;
+    int64_t n = 0;
+};
+
+struct pcr_index {
+    int kind = PCR_INDEX_GRID;
+    int64_t n = 0;
+    double cell = 0;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    // GRID
+    pcr_pt* sorted = nullptr;
+    pcr_cell_slot* tables[PCR_MAX_LEVELS] = {nullptr};
+    unsigned int caps[PCR_MAX_LEVELS] = {0};
+    pcr_grid_view view;
+    // BRUTE (f64 MFMA operand layout): tiles of 16 targets, 64 doubles per tile in lane order
+    double* mfma_a = nullptr;   // [n_tiles][64]
+    pcr_pt* plain = nullptr;    // targets in original order, centred copy not needed (exact recheck uses these)
+    int64_t n_tiles = 0;
+};
+
+struct pcr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    std::string last_error;
+    // grow-only caching allocator (device) keyed by size; avoids hipMalloc in the ICP loop
+    struct blk { void* p; size_t sz; };
+    std::vector<blk> free_list;
+    // pinned host scratch for the per-iteration moment read-back
+    double* h_pinned = nullptr;
+    size_t h_pinned_bytes = 0;
+    // device scratch for per-block partial moments
+    double* d_partials = nullptr;
+    size_t d_partials_bytes = 0;
+    unsigned int* d_counters = nullptr;  // small zeroed scratch (tickets, flags)
+    int cu_count = 256;
+    char name[256] = {0};
+    int64_t hbm_bytes = 0;
+};
+
+#define PCR_HIP(ctx, expr)                                                            \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);    \
+            return PCR_E_HIP;                                                         \
+        }                                                                             \
+    } while (0)
+
+PCR_HIDDEN int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out);
+PCR_HIDDEN void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes);
+PCR_HIDDEN int pcr_ensure_scratch(pcr_ctx* ctx, size_t partial_bytes);
+PCR_HIDDEN void pcr_xform_from_T(const double* T, pcr_xform* x);
+
+// grid (pcr_grid.hip)
+PCR_HIDDEN int pcr_bbox(pcr_ctx* ctx, const pcr_pt* pts, long long n, double lo[3], double hi[3]);
+PCR_HIDDEN int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* idx);
+PCR_HIDDEN void pcr_grid_free(pcr_ctx* ctx, pcr_index* idx);
+PCR_HIDDEN int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, const pcr_pt* q, int64_t nq, const pcr_xform* x,
+                            double max_d2, int32_t* d_idx, double* d_d2);
+// One fused association+accumulate pass.  If write_back, q[i] <- x(q[i]) (in-place transform).
+// d_moments receives 20 doubles: 18 moments + sum d2 + (unused).
+PCR_HIDDEN int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, const pcr_xform* x,
+                                 double max_d2, int write_back, double* d_moments);
+// brute (pcr_brute.hip)
+PCR_HIDDEN int pcr_brute_build(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_index* idx);
+PCR_HIDDEN void pcr_brute_free(pcr_ctx* ctx, pcr_index* idx);
+PCR_HIDDEN int pcr_brute_nn1(pcr_ctx* ctx, const pcr_index* idx, const pcr_pt* q, int64_t nq, const pcr_xform* x,
+                             double max_d2, int32_t* d_idx, double* d_d2);
+PCR_HIDDEN int pcr_brute_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, const pcr_xform* x,
+                                  double max_d2, int write_back, double* d_moments);
+
+constexpr int PCR_NMOM = 20;  // K, Sa[3], Sb[3], Sba[9], Saa, Sbb, Sd2, pad

@@ -1,0 +1,159 @@
+"""GPU parity tests (run on the MI355X box): HIP path vs the CPU oracle and the
+reference goldens, through the C ABI (ctypes -> libpcr.so)."""
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TIE_MARGIN = 1e-12  # queries whose two nearest targets are closer than this (relative d2) are ties
+
+
+def _check_nn(idx, d2, q, t, oracle, gate=None):
+    oi, od2, margin = oracle.nn1_exact(q, t)
+    if gate is not None:
+        gated = od2 < gate
+        assert np.array_equal(idx >= 0, gated)
+        sel = gated
+    else:
+        sel = np.ones(len(q), bool)
+    clear = sel & (margin > TIE_MARGIN)
+    assert np.array_equal(idx[clear], oi[clear])
+    # squared distances are bit-identical to the direct form evaluated on the host
+    assert np.array_equal(d2[sel], od2[sel])
+    return int((~clear & sel).sum())
+
+
+@pytest.mark.parametrize("kind", ["grid", "brute"])
+def test_nn1_small_uniform(pcp, oracle, kind):
+    rng = np.random.default_rng(0)
+    t = rng.uniform(-1, 1, (3000, 3))
+    q = rng.uniform(-1.2, 1.2, (1777, 3))
+    index = pcp.TargetIndex(t, kind=kind)
+    idx, d2 = index.nn1(q)
+    _check_nn(idx, d2, q, t, oracle)
+    idx, d2 = index.nn1(q, max_d2=0.002)
+    _check_nn(idx, d2, q, t, oracle, gate=0.002)
+
+
+@pytest.mark.parametrize("kind", ["grid", "brute"])
+def test_nn1_kitti_20k_with_transform(pcp, oracle, syn, kind):
+    src, tgt, Tt = syn.perturbed_pair(20000, seed=7)
+    index = pcp.TargetIndex(tgt, kind=kind)
+    T = syn.rigid_transform((0.1, 0.2, 1.0), 0.01, (0.1, 0.0, 0.0))
+    idx, d2 = index.nn1(src, T=T, max_d2=5.0)
+    moved = src.astype(np.float64)
+    moved = np.stack([
+        ((T[0, 0] * moved[:, 0] + T[0, 1] * moved[:, 1]) + T[0, 2] * moved[:, 2]) + T[0, 3],
+        ((T[1, 0] * moved[:, 0] + T[1, 1] * moved[:, 1]) + T[1, 2] * moved[:, 2]) + T[1, 3],
+        ((T[2, 0] * moved[:, 0] + T[2, 1] * moved[:, 1]) + T[2, 2] * moved[:, 2]) + T[2, 3]], axis=1)
+    _check_nn(idx, d2, moved, tgt.astype(np.float64), oracle, gate=5.0)
+
+
+def test_nn1_edge_cases(pcp, oracle):
+    rng = np.random.default_rng(3)
+    # single target point, queries far outside the grid, duplicate targets, collinear cloud
+    t1 = np.array([[1.0, 2.0, 3.0]])
+    q = rng.normal(0, 50, (100, 3))
+    for kind in ("grid", "brute"):
+        idx, d2 = pcp.TargetIndex(t1, kind=kind).nn1(q)
+        assert (idx == 0).all() and np.array_equal(d2, oracle.dist2_direct(q, t1[0]))
+    t = rng.uniform(0, 1, (500, 3))
+    far = rng.uniform(0, 1, (64, 3)) + np.array([1e4, -3e3, 10.0])
+    for kind in ("grid", "brute"):
+        idx, d2 = pcp.TargetIndex(t, kind=kind).nn1(far)
+        bi, bd2 = oracle.nn1_bruteforce(far, t)
+        assert np.array_equal(d2, bd2)
+    dup = np.concatenate([t, t[:50]])
+    for kind in ("grid", "brute"):
+        idx, d2 = pcp.TargetIndex(dup, kind=kind).nn1(t[:50] + 1e-9)
+        assert np.array_equal(idx, np.arange(50))  # exact ties resolve to the lowest index
+    line = np.c_[np.linspace(0, 10, 400), np.zeros(400), np.zeros(400)]
+    for kind in ("grid", "brute"):
+        idx, d2 = pcp.TargetIndex(line, kind=kind).nn1(line + np.array([0.004, 0.3, -0.2]))
+        bi, bd2 = oracle.nn1_bruteforce(line + np.array([0.004, 0.3, -0.2]), line)
+        assert np.array_equal(d2, bd2)
+
+
+def test_empty_cloud_is_an_error(pcp):
+    with pytest.raises(RuntimeError):
+        pcp.TargetIndex(np.zeros((0, 3)))
+
+
+@pytest.mark.parametrize("kind", ["grid", "brute"])
+def test_fused_moments_match_oracle(pcp, oracle, syn, kind):
+    src, tgt, Tt = syn.perturbed_pair(20000, seed=11)
+    index = pcp.TargetIndex(tgt, kind=kind)
+    m, origin, sum_d2 = index.moments(src, None, 5.0)
+    s64, t64 = src.astype(np.float64), tgt.astype(np.float64)
+    oi, od2, _ = oracle.nn1_exact(s64, t64)
+    keep = od2 < 5.0
+    ref = oracle.moments(s64[keep], t64[oi[keep]], origin)
+    assert m[0] == ref[0]
+    assert np.allclose(m, ref, rtol=1e-11, atol=1e-9)
+    assert abs(sum_d2 - od2[keep].sum()) < 1e-9 * od2[keep].sum()
+    # bitwise reproducible run to run (fixed reduction order)
+    m2, _, s2 = index.moments(src, None, 5.0)
+    assert np.array_equal(m, m2) and s2 == sum_d2
+
+
+@pytest.mark.parametrize("kind", ["grid", "brute"])
+def test_icp_compat_matches_reference_goldens(pcp, kind, capsys):
+    """icp_point2point vs the outputs of the reference's own Registration/main.py:icp_point2point."""
+    g = load_golden("icp_compat.npz")
+    for tag in g["cases"]:
+        tag = str(tag)
+        src = pcp.PointCloud(g[f"{tag}_src"])
+        T, info = pcp.icp_point2point(src, g[f"{tag}_tgt"], g[f"{tag}_T0"], nn=kind, return_info=True)
+        assert info["iters"] == int(g[f"{tag}_iters"][0]), tag
+        assert np.linalg.norm(T - g[f"{tag}_T"]) < 1e-4, tag  # BASELINE.json: 1e-4 Frobenius on R|t
+        assert np.linalg.norm(T - g[f"{tag}_T"]) < 1e-9, tag  # what the f64 path actually achieves
+        assert np.abs(src.points - g[f"{tag}_src_after"]).max() < 1e-9, tag  # in-place side effect (main.py:110)
+        failed = int(g[f"{tag}_failed"][0])
+        assert (info["status"] == 1) == bool(failed), tag
+    assert "ICP failed, cannot find enough associations!" in capsys.readouterr().out
+
+
+def test_icp_total_matches_oracle(pcp, oracle, syn):
+    src, tgt, Tt = syn.perturbed_pair(20000, seed=5)
+    T, log = pcp.ICP(src, tgt, max_iteration=30)
+    To, logo = oracle.icp_total(src, tgt, max_iteration=30)
+    assert len(log["R_diff"]) == len(logo["R_diff"])
+    assert np.linalg.norm(T - To) < 1e-8
+    assert np.allclose(log["t_diff"], logo["t_diff"], atol=1e-9)
+    # and it actually registers the pair
+    assert np.linalg.norm(T[:3, 3] - Tt[:3, 3]) < 0.05
+
+
+def test_icp_120k_full_size_properties(pcp, oracle, syn):
+    """BASELINE config 2 size: grid and brute-force paths agree with each other and with the CPU oracle."""
+    src, tgt, Tt = syn.perturbed_pair(120000, seed=0)
+    ig = pcp.TargetIndex(tgt, kind="grid")
+    ib = pcp.TargetIndex(tgt, kind="brute")
+    idx_g, d2_g = ig.nn1(src, max_d2=5.0)
+    idx_b, d2_b = ib.nn1(src, max_d2=5.0)
+    oi, od2, margin = oracle.nn1_exact(src.astype(np.float64), tgt.astype(np.float64), workers=-1)
+    sel = od2 < 5.0
+    assert np.array_equal(idx_g >= 0, sel) and np.array_equal(idx_b >= 0, sel)
+    assert np.array_equal(d2_g[sel], od2[sel]) and np.array_equal(d2_b[sel], od2[sel])
+    clear = sel & (margin > TIE_MARGIN)
+    assert np.array_equal(idx_g[clear], oi[clear]) and np.array_equal(idx_b[clear], oi[clear])
+    Tg = pcp.icp_point2point(pcp.PointCloud(src), ig, np.eye(4))
+    Tb = pcp.icp_point2point(pcp.PointCloud(src), ib, np.eye(4))
+    To = oracle.icp_point2point(src, tgt, np.eye(4))["T"]
+    assert np.linalg.norm(Tg - To) < 1e-9 and np.linalg.norm(Tb - To) < 1e-9
+
+
+def test_procrustes_and_pose_utils(pcp):
+    g = load_golden("procrustes.npz")
+    for key in ("K3", "K10", "K500", "K3000", "refl"):
+        R, t, cost = pcp.procrustes_transformation(g[f"{key}_A"], g[f"{key}_B"])
+        assert R.shape == (3, 3) and t.shape == (3, 1)
+        assert np.abs(R - g[f"{key}_R"]).max() < 1e-9, key
+        assert np.abs(t - g[f"{key}_t"]).max() < 1e-9, key
+        assert abs(cost - g[f"{key}_cost"][0]) < 1e-7 * max(1.0, cost), key
+    p = load_golden("pose_utils.npz")
+    for T, tq in zip(p["T"], p["tq"]):
+        assert np.allclose(pcp.homo2tq(T), tq, rtol=0, atol=1e-15)
+        assert np.allclose(pcp.rotmat2quaternion(T[:3, :3]), tq[3:], rtol=0, atol=1e-15)

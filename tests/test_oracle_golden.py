@@ -1,0 +1,77 @@
+"""The CPU oracle (oracle/oracle_np.py) pinned against outputs of the reference's own
+functions (tests/golden/*.npz, produced by oracle/ref_harness.py in the build container)."""
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+
+
+def test_voxel_keys_bit_exact_and_centroids(oracle):
+    g = load_golden("voxel_filter.npz")
+    for tag in g["cases"]:
+        tag = str(tag)
+        cname, leaf = tag.split("_leaf")
+        pts = g[f"{cname}_in"]
+        h, D = oracle.voxel_keys(pts, float(leaf))
+        assert np.array_equal(D, g[f"{tag}_D"]), tag
+        assert np.array_equal(h, g[f"{tag}_h"]), tag  # bit-exact float64 keys
+        cen, order, starts, ends = oracle.voxel_filter(pts, float(leaf), "centroid")
+        ref = g[f"{tag}_centroid"]
+        assert cen.shape == ref.shape, tag  # occupied voxels - 1 (drop-last quirk)
+        assert np.array_equal(cen, ref), tag  # same np.mean on the same groups -> bitwise
+        # "random": every reference output row is a member of the corresponding voxel
+        rnd = g[f"{tag}_random"]
+        assert rnd.shape == ref.shape
+        for r, (s, e) in zip(rnd, zip(starts[:-1], ends[:-1])):
+            assert (pts[order[s:e]] == r).all(axis=1).any()
+
+
+def test_voxel_single_voxel_is_empty(oracle):
+    g = load_golden("voxel_filter.npz")
+    cen, *_ = oracle.voxel_filter(g["onevoxel_in"], 1.0, "centroid")
+    assert cen.shape[0] == 0
+    assert tuple(g["onevoxel_centroid_shape"]) == (0,)
+
+
+def test_icp_compat_matches_reference(oracle):
+    g = load_golden("icp_compat.npz")
+    for tag in g["cases"]:
+        tag = str(tag)
+        r = oracle.icp_point2point(g[f"{tag}_src"], g[f"{tag}_tgt"], g[f"{tag}_T0"])
+        assert r["iters"] == int(g[f"{tag}_iters"][0]), tag
+        assert int(r["failed"]) == int(g[f"{tag}_failed"][0]), tag
+        assert np.linalg.norm(r["T"] - g[f"{tag}_T"]) < 1e-9, tag
+        assert np.abs(r["src_after"] - g[f"{tag}_src_after"]).max() < 1e-9, tag
+
+
+def test_procrustes_matches_literal_L_matrix(oracle):
+    g = load_golden("procrustes.npz")
+    for key in ("K3", "K10", "K500", "K3000", "refl"):
+        R, t, cost = oracle.procrustes(g[f"{key}_A"], g[f"{key}_B"])
+        assert np.abs(R - g[f"{key}_R"]).max() < 1e-9, key
+        assert np.abs(t - g[f"{key}_t"]).max() < 1e-9, key
+        assert abs(cost - g[f"{key}_cost"][0]) < 1e-7 * max(1.0, cost), key
+    assert np.linalg.det(g["refl_R"]) < 0  # the reference applies no reflection fix
+
+
+def test_pose_utils(oracle):
+    g = load_golden("pose_utils.npz")
+    for T, tq in zip(g["T"], g["tq"]):
+        assert np.allclose(oracle.homo2tq(T), tq, rtol=0, atol=1e-15)
+
+
+def test_knn_radius_match_reference_trees(oracle):
+    g = load_golden("nn_api.npz")
+    for name, rads in (("rand64", (0.25, 0.5)), ("kitti4000", (0.5, 1.0))):
+        db = g[f"{name}_db"]
+        for qi, q in enumerate(g[f"{name}_queries"]):
+            for k in (1, 8):
+                idx, dist = oracle.knn_bruteforce(db, q, k)
+                for tree in ("kd", "oct"):
+                    assert np.array_equal(idx, g[f"{name}_{tree}_knn{k}_idx"][qi]), (name, tree, k, qi)
+                    assert np.allclose(dist, g[f"{name}_{tree}_knn{k}_dist"][qi], rtol=1e-14, atol=0)
+            for rad in rads:
+                idx, dist = oracle.radius_bruteforce(db, q, rad)
+                for tree in ("kd", "oct", "octfast"):
+                    assert np.array_equal(idx, g[f"{name}_{tree}_rad{rad}_q{qi}_idx"]), (name, tree, rad, qi)
+                    assert np.allclose(dist, g[f"{name}_{tree}_rad{rad}_q{qi}_dist"], rtol=1e-14, atol=0)
