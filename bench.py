@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Benchmark of the registration hot path (BASELINE.json metric).
+
+A "step" is one point-to-point ICP iteration on a 120 000 x 120 000-point
+KITTI-shaped synthetic scan pair (BASELINE.json configs[1]): in-place source
+transform + exact 1-NN of every source point + d2 < 5 gate + Procrustes moment
+accumulation on the GPU, 160-byte read-back, 3x3 SVD on the host.  Inputs and
+the target index are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--nn grid|brute]
+
+N > 1 is launched by torch.distributed.run (one process per GPU): every rank
+registers its own independent pair (the path shards across pairs, never inside
+one), results are gathered with one all_gather over RCCL, the
+timing is the max over ranks.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_POINTS = 120_000
+MAX_D2 = 5.0
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix; scripts/mfma_f64_peak measures the achievable rate
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic HBM bytes per correspondence of the grid pass:
+# 32 B source record read + 32 B written back in place + 32 B matched target record + 4 B result slot
+GRID_BYTES_PER_CORR = 100.0
+
+
+def cpu_baseline(src, tgt, budget_s=12.0, max_iters=40):
+    """Reference-equivalent CPU path (oracle, kind "port"): scipy cKDTree exact 1-NN on all
+    host cores + NumPy mean-subtraction Procrustes, same gate and loop as main.py:105-146."""
+    oracle = importlib.import_module("oracle.oracle_np")
+    from scipy.spatial import cKDTree
+
+    cores = len(os.sched_getaffinity(0))
+    s = src.astype(np.float64)
+    t = tgt.astype(np.float64)
+    t0 = time.perf_counter()
+    tree = cKDTree(t)
+    build_s = time.perf_counter() - t0
+    T = np.eye(4)
+    iters = 0
+    t0 = time.perf_counter()
+    while iters < max_iters and (time.perf_counter() - t0) < budget_s:
+        s = s @ T[:3, :3].T + T[:3, 3]
+        _, j = tree.query(s, k=1, workers=-1)
+        d2 = oracle.dist2_direct(s, t[j])
+        keep = d2 < MAX_D2
+        R, tt, _ = oracle.procrustes(s[keep].T, t[j[keep]].T)
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = tt.squeeze()
+        iters += 1
+    el = time.perf_counter() - t0
+    return {
+        "value": len(src) * iters / el,
+        "unit": "correspondences/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{iters} ICP iterations on the same 120k x 120k pair (scipy cKDTree workers=-1 + NumPy Procrustes), "
+                  f"{el:.1f} s; one-off tree build {build_s * 1e3:.0f} ms not counted",
+        "ms_per_iter": 1e3 * el / iters,
+    }
+
+
+def run_icp_steps(pkg, index, src_host, steps, ctx):
+    """Exactly `steps` ICP iterations (thresholds off), device-resident inputs.  Returns dict."""
+    out = {"iters": 0, "device_ms": 0.0, "nn_kernel_ms": 0.0, "nn_launches": 0}
+    sd = pkg.DeviceCloud.upload(src_host, ctx)
+    T0 = np.eye(4)
+    ctx.sync()
+    t0 = time.perf_counter()
+    left = steps
+    last = None
+    while left > 0:
+        k = min(left, 256)
+        r = pkg.icp_device(sd, index, T0, mode="total", max_iter=k, r_thres=-1.0, t_thres=-1.0, max_d2=MAX_D2, min_iter=k)
+        T0 = np.eye(4)  # later chunks continue from the already-transformed source
+        for key in ("iters", "device_ms", "nn_kernel_ms", "nn_launches"):
+            out[key] += r[key]
+        last = r
+        left -= k
+    ctx.sync()
+    out["wall_s"] = time.perf_counter() - t0
+    out["n_assoc"] = last["n_assoc"]
+    out["T_total"] = last["T_total"]
+    sd.free()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nn", default="grid", choices=["grid", "brute"])
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-brute", action="store_true", help="skip the brute-force MFMA leg")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    pkg = importlib.import_module("point-cloud-process_amd")
+    ctx = pkg.Context(local_rank)
+    syn = pkg.synthetic
+
+    # every rank registers its own pair (different seed); same size => weak scaling
+    src, tgt, T_true = syn.perturbed_pair(a.points, seed=rank)
+    index = pkg.TargetIndex(pkg.DeviceCloud.upload(tgt, ctx), kind=a.nn, ctx=ctx)
+    ctx.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    run_icp_steps(pkg, index, src, a.warmup, ctx)  # untimed warm-up
+    barrier()
+    t0 = time.perf_counter()
+    r = run_icp_steps(pkg, index, src, a.steps, ctx)
+    # result gather: 16 doubles + iters + n_assoc per rank (RCCL all_gather), inside the timed region
+    if dist is not None:
+        rec = torch.zeros(18, dtype=torch.float64, device=f"cuda:{local_rank}")
+        rec[:16] = torch.from_numpy(r["T_total"].reshape(16))
+        rec[16] = r["iters"]
+        rec[17] = r["n_assoc"]
+        allrec = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        n_src = a.points
+        corr_total = float(n_src) * a.steps * world
+        value = corr_total / elapsed
+        # per-kernel profile (HIP events on the library's stream) in a separate, untimed run
+        ctx.profile(True)
+        rp = run_icp_steps(pkg, index, src, min(a.steps, 50), ctx)
+        prof_ms, passes = ctx.profile_read()
+        ctx.profile(False)
+        kern = {}
+        if a.nn == "grid":
+            names = ["grid_phase1_kernel", "grid_phase2_kernel", "grid_accumulate_kernel", "reduce_partials_kernel"]
+        else:
+            names = ["brute_nn_kernel", "brute_merge_kernel", "-", "brute_reduce_partials_kernel"]
+        for nm, ms in zip(names, prof_ms):
+            if nm != "-":
+                kern[nm] = ms / max(passes, 1) * 1e3  # us per launch
+        dom = max(kern, key=kern.get)
+        dom_s = kern[dom] * 1e-6
+        if a.nn == "grid":
+            algo_bytes = GRID_BYTES_PER_CORR * n_src
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": algo_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo_bytes / dom_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "working set (2 x 3.8 MB) is L2/MALL resident; this kernel is latency/issue bound, not HBM bound"}
+        else:
+            flops = 8.0 * n_src * a.points
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": flops / dom_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / dom_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None}
+        line = {
+            "metric": "correspondence-pairs/sec + ms/ICP-iter, 120k-pt KITTI pair",
+            "value": value,
+            "unit": "correspondences/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"point-to-point ICP iteration, {n_src} x {a.points} KITTI-shaped synthetic scan pair per GPU "
+                                   f"(BASELINE configs[1]); exact 1-NN via {a.nn}", "nn": a.nn, "pairs_per_gpu": 1,
+                       "points_src": n_src, "points_tgt": a.points, "max_d2": MAX_D2, "cell_m": index.cell},
+            "ms_per_icp_iter": 1e3 * elapsed / a.steps,
+            "device_ms_per_iter": r["device_ms"] / r["iters"],
+            "pass_kernels_ms_per_iter": r["nn_kernel_ms"] / max(r["nn_launches"], 1),
+            "kernel_us": kern,
+            "n_assoc_last": int(r["n_assoc"]),
+            "roofline": roofline,
+        }
+        if a.nn == "brute":
+            line["candidate_pairs_per_s"] = float(n_src) * a.points * a.steps * world / elapsed
+        # brute-force MFMA leg (candidate pairs/s + MFMA roofline), N = 1 only
+        if world == 1 and a.nn == "grid" and not a.no_brute:
+            ib = pkg.TargetIndex(pkg.DeviceCloud.upload(tgt, ctx), kind="brute", ctx=ctx)
+            run_icp_steps(pkg, ib, src, 2, ctx)
+            ctx.profile(True)
+            kb = 10
+            t1 = time.perf_counter()
+            rb = run_icp_steps(pkg, ib, src, kb, ctx)
+            eb = time.perf_counter() - t1
+            pm, pp = ctx.profile_read()
+            ctx.profile(False)
+            sweep_s = pm[0] / max(pp, 1) * 1e-3
+            flops = 8.0 * n_src * a.points
+            line["brute_mfma"] = {
+                "ms_per_icp_iter": 1e3 * eb / kb,
+                "correspondences_per_s": n_src * kb / eb,
+                "candidate_pairs_per_s": float(n_src) * a.points / sweep_s,
+                "roofline": {"bound": "mfma", "kernel": "brute_nn_kernel", "achieved": flops / sweep_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": flops / sweep_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                             "dtype": "f64 (v_mfma_f64_16x16x4_f64)"},
+            }
+            ib.free()
+        if world == 1 and not a.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(src, tgt)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -179,6 +179,11 @@ PCR_API int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, double 
  * HIP-event stopwatch on the ctx stream, for bench.py's roofline figures.   */
 PCR_API int pcr_timer_start(pcr_ctx* ctx);
 PCR_API int pcr_timer_stop_ms(pcr_ctx* ctx, double* ms_out);
+/* Per-kernel HIP-event profile of the ICP pass (adds one event sync per pass while on).
+ * slots: 0 = search phase 1 (grid) / MFMA sweep (brute), 1 = search phase 2 (grid) / merge (brute),
+ *        2 = accumulate, 3 = reduce.  ms_out[4] = summed milliseconds, *passes_out = passes profiled. */
+PCR_API int pcr_profile_enable(pcr_ctx* ctx, int on);
+PCR_API int pcr_profile_read(pcr_ctx* ctx, double ms_out[4], int* passes_out);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,8 @@ SIGNATURES = {
     "pcr_voxel_filter": (C.c_int, [_vp, _dp, C.c_int64, C.c_double, C.c_int, C.c_uint64, _dp, _lp]),
     "pcr_voxel_filter_cloud": (C.c_int, [_vp, _vp, C.c_double, C.c_int, C.c_uint64, C.POINTER(_vp)]),
     "pcr_iss": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _ip, _ip, C.POINTER(C.c_int)]),
+    "pcr_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "pcr_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "pcr_timer_start": (C.c_int, [_vp]),
     "pcr_timer_stop_ms": (C.c_int, [_vp, _dp]),
 }

@@ -271,10 +271,12 @@ static int brute_search(pcr_ctx* ctx, const pcr_index* idx, const pcr_pt* q, int
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
     dim3 grid((unsigned)((nq + BR_QPB - 1) / BR_QPB), (unsigned)splits);
+    pcr_prof_mark(ctx, 0);
     hipLaunchKernelGGL(brute_nn_kernel, grid, dim3(256), 0, ctx->stream, (const double*)idx->mfma_a, (const pcr_pt*)idx->plain,
                        (long long)idx->n, (long long)idx->n_tiles, splits, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
                        idx->view.origin[0], idx->view.origin[1], idx->view.origin[2], cand);
     PCR_HIP(ctx, hipGetLastError());
+    pcr_prof_mark(ctx, 1);
     *cand_out = cand;
     *splits_out = splits;
     return PCR_OK;
@@ -310,8 +312,12 @@ int pcr_brute_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq
     hipLaunchKernelGGL(brute_merge_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, (const brute_cand*)cand, splits, q, (long long)nq, *x,
                        1, (const pcr_pt*)idx->plain, max_d2, gated ? 1 : 0, write_back, idx->view.origin[0], idx->view.origin[1],
                        idx->view.origin[2], (int*)nullptr, (double*)nullptr, ctx->d_partials);
+    pcr_prof_mark(ctx, 2);
+    pcr_prof_mark(ctx, 3);
     hipLaunchKernelGGL(brute_reduce_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ctx->d_partials, grid, d_moments);
+    pcr_prof_mark(ctx, 4);
     PCR_HIP(ctx, hipGetLastError());
+    pcr_prof_finish(ctx);
     pcr_dev_free(ctx, cand, sizeof(brute_cand) * (size_t)splits * nq);
     return PCR_OK;
 }

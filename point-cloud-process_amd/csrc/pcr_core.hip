@@ -68,6 +68,8 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     hipEventDestroy(c->ev1);
     hipEventDestroy(c->ev2);
     hipEventDestroy(c->ev3);
+    for (int i = 0; i < 5; ++i)
+        if (c->pev[i]) hipEventDestroy(c->pev[i]);
     hipStreamDestroy(c->stream);
     delete c;
     return PCR_OK;
@@ -84,6 +86,23 @@ int pcr_ctx_device_info(pcr_ctx* c, char* name256, int* cu, int64_t* hbm) {
     if (name256) { strncpy(name256, c->name, 255); name256[255] = 0; }
     if (cu) *cu = c->cu_count;
     if (hbm) *hbm = c->hbm_bytes;
+    return PCR_OK;
+}
+
+int pcr_profile_enable(pcr_ctx* c, int on) {
+    if (!c) return PCR_E_INVALID;
+    if (on && !c->pev[0])
+        for (int i = 0; i < 5; ++i) PCR_HIP(c, hipEventCreate(&c->pev[i]));
+    c->profile = on != 0;
+    for (int i = 0; i < 4; ++i) c->prof_ms[i] = 0;
+    c->prof_passes = 0;
+    return PCR_OK;
+}
+
+int pcr_profile_read(pcr_ctx* c, double ms_out[4], int* passes_out) {
+    if (!c || !ms_out) return PCR_E_INVALID;
+    for (int i = 0; i < 4; ++i) ms_out[i] = c->prof_ms[i];
+    if (passes_out) *passes_out = c->prof_passes;
     return PCR_OK;
 }
 
@@ -104,6 +123,20 @@ int pcr_timer_stop_ms(pcr_ctx* c, double* ms) {
 }
 
 }  // extern "C"
+
+void pcr_prof_mark(pcr_ctx* ctx, int k) {
+    if (ctx->profile) hipEventRecord(ctx->pev[k], ctx->stream);
+}
+
+void pcr_prof_finish(pcr_ctx* ctx) {
+    if (!ctx->profile) return;
+    hipEventSynchronize(ctx->pev[4]);
+    for (int i = 0; i < 4; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->pev[i], ctx->pev[i + 1]) == hipSuccess) ctx->prof_ms[i] += ms;
+    }
+    ctx->prof_passes += 1;
+}
 
 // ------------------------------------------------------------------ memory
 int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out) {

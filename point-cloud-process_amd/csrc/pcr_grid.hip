@@ -693,12 +693,14 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
     const int block = 256;
     const long long threads = (long long)nq * P1_G;
     const int grid1 = (int)((threads + block - 1) / block);
+    pcr_prof_mark(ctx, 0);
     hipLaunchKernelGGL(grid_phase1_kernel, dim3(grid1), dim3(block), 0, ctx->stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
                        write_back, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, sc->work, sc->work_count);
     // phase 2: a fixed grid of waves walks the work list (its length is only known on the device)
     long long waves = nq < 8ll * 4 * ctx->cu_count ? nq : 8ll * 4 * ctx->cu_count;
     int grid2 = (int)((waves + 3) / 4);
     if (grid2 < 1) grid2 = 1;
+    pcr_prof_mark(ctx, 1);
     hipLaunchKernelGGL(grid_phase2_kernel, dim3(grid2), dim3(256), 0, ctx->stream, idx->view, (const work_item*)sc->work,
                        (const unsigned int*)sc->work_count, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2);
     PCR_HIP(ctx, hipGetLastError());
@@ -735,10 +737,14 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq,
     if (grid > 4 * ctx->cu_count) grid = 4 * ctx->cu_count;
     if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid))) return rc;
     // after a write-back pass q already holds the transformed points
+    pcr_prof_mark(ctx, 2);
     hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)q, (long long)nq, *x,
                        write_back ? 0 : 1, (const unsigned int*)sc.res_pos, max_d2, gated ? 1 : 0, ctx->d_partials);
+    pcr_prof_mark(ctx, 3);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ctx->d_partials, grid, d_moments);
+    pcr_prof_mark(ctx, 4);
     PCR_HIP(ctx, hipGetLastError());
+    pcr_prof_finish(ctx);
     grid_scratch_free(ctx, &sc);
     return PCR_OK;
 }

@@ -80,6 +80,11 @@ struct pcr_ctx {
     double* d_partials = nullptr;
     size_t d_partials_bytes = 0;
     unsigned int* d_counters = nullptr;  // small zeroed scratch (tickets, flags)
+    // optional per-kernel profile of the ICP pass
+    bool profile = false;
+    hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double prof_ms[4] = {0, 0, 0, 0};
+    int prof_passes = 0;
     int cu_count = 256;
     char name[256] = {0};
     int64_t hbm_bytes = 0;
@@ -98,6 +103,9 @@ PCR_HIDDEN int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out);
 PCR_HIDDEN void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes);
 PCR_HIDDEN int pcr_ensure_scratch(pcr_ctx* ctx, size_t partial_bytes);
 PCR_HIDDEN void pcr_xform_from_T(const double* T, pcr_xform* x);
+// profile helpers: mark slot boundary k (0..4) on the stream; finish() syncs and accumulates
+PCR_HIDDEN void pcr_prof_mark(pcr_ctx* ctx, int k);
+PCR_HIDDEN void pcr_prof_finish(pcr_ctx* ctx);
 
 // grid (pcr_grid.hip)
 PCR_HIDDEN int pcr_bbox(pcr_ctx* ctx, const pcr_pt* pts, long long n, double lo[3], double hi[3]);

@@ -44,6 +44,15 @@ class Context:
         L.check(L.lib().pcr_timer_stop_ms(self.handle, C.byref(ms)), self.handle)
         return ms.value
 
+    def profile(self, on=True):
+        L.check(L.lib().pcr_profile_enable(self.handle, 1 if on else 0), self.handle)
+
+    def profile_read(self):
+        ms = np.zeros(4)
+        n = C.c_int()
+        L.check(L.lib().pcr_profile_read(self.handle, L.dptr(ms), C.byref(n)), self.handle)
+        return ms, n.value
+
     def close(self):
         if self._h:
             L.lib().pcr_ctx_destroy(self._h)
