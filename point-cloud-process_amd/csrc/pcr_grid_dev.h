@@ -1,0 +1,82 @@
+// Device-side helpers shared by the grid build and search kernels.
+#pragma once
+#include <cfloat>
+#include "pcr_internal.h"
+
+constexpr unsigned int POS_NONE = 0xffffffffu;
+
+struct __attribute__((aligned(16))) work_item {  // a query handed from one search stage to the next
+    double ax, ay, az;   // transformed query
+    double best_d2;      // best squared distance so far (DBL_MAX = none)
+    unsigned int best_pos;
+    unsigned int qi;
+};
+
+__host__ __device__ static inline unsigned long long spread21(unsigned long long x) {
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__host__ __device__ static inline unsigned int compact21(unsigned long long x) {
+    x &= 0x1249249249249249ull;
+    x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ull;
+    x = (x ^ (x >> 4)) & 0x100f00f00f00f00full;
+    x = (x ^ (x >> 8)) & 0x1f0000ff0000ffull;
+    x = (x ^ (x >> 16)) & 0x1f00000000ffffull;
+    x = (x ^ (x >> 32)) & 0x1fffffull;
+    return (unsigned int)x;
+}
+
+// level-0 integer cell coordinate (biased by 2^20, clamped to 21 bits).  *clamped is set
+// when the point lies outside the representable range (then only a full descent is exact).
+__device__ static inline int cell_coord(double v, double lo, double inv, bool* clamped) {
+    const double f = floor((v - lo) * inv);
+    if (!(f >= -(double)(PCR_COORD_BIAS)) || !(f <= (double)(PCR_COORD_MAX - PCR_COORD_BIAS))) {  // also NaN
+        *clamped = true;
+        return f > 0 ? (int)PCR_COORD_MAX : 0;
+    }
+    return (int)f + (int)PCR_COORD_BIAS;
+}
+
+__device__ static inline unsigned int cell_hash(unsigned int x, unsigned int y, unsigned int z) {
+    return (x * 73856093u) ^ (y * 19349663u) ^ (z * 83492791u);
+}
+
+__device__ static inline unsigned long long cell_pack(unsigned int x, unsigned int y, unsigned int z) {
+    return (unsigned long long)x | ((unsigned long long)y << 21) | ((unsigned long long)z << 42);
+}
+
+__device__ static inline bool lookup_cell(const pcr_cell_slot* __restrict__ tab, unsigned int mask, unsigned int x, unsigned int y,
+                                          unsigned int z, unsigned int* s, unsigned int* e) {
+    const unsigned long long key = cell_pack(x, y, z);
+    unsigned int h = cell_hash(x, y, z) & mask;
+    for (unsigned int probe = 0; probe <= mask; ++probe) {
+        const pcr_cell_slot sl = tab[h];
+        if (sl.key == key) { *s = sl.start; *e = sl.end; return true; }
+        if (sl.key == PCR_EMPTY_KEY) return false;
+        h = (h + 1) & mask;
+    }
+    return false;
+}
+
+__device__ static inline bool better(double d2, long long id, double bd2, long long bid) {
+    return d2 < bd2 || (d2 == bd2 && id < bid);
+}
+
+// Exact squared distance, evaluated exactly like the host check:
+// (dx*dx + dy*dy) + dz*dz with each operation rounded (no FMA: -ffp-contract=off).
+__device__ static inline double dist2(double ax, double ay, double az, const pcr_pt& b) {
+    const double dx = ax - b.x, dy = ay - b.y, dz = az - b.z;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+__device__ static inline void xform_apply(const pcr_xform& x, const pcr_pt& p, double* ax, double* ay, double* az) {
+    *ax = ((x.r[0] * p.x + x.r[1] * p.y) + x.r[2] * p.z) + x.t[0];
+    *ay = ((x.r[3] * p.x + x.r[4] * p.y) + x.r[5] * p.z) + x.t[1];
+    *az = ((x.r[6] * p.x + x.r[7] * p.y) + x.r[8] * p.z) + x.t[2];
+}
