@@ -67,6 +67,9 @@ PCR_API int pcr_cloud_upload_f64(pcr_ctx* ctx, const double* xyz, int64_t n, int
 PCR_API int pcr_cloud_download_f64(pcr_ctx* ctx, const pcr_cloud* cloud, double* xyz_out /* n*3 */);
 PCR_API int64_t pcr_cloud_size(const pcr_cloud* cloud);
 PCR_API int pcr_cloud_free(pcr_ctx* ctx, pcr_cloud* cloud);
+/* Optional: lay the cloud out for queries against `index` now (Morton order of its records; row
+ * ids are kept, downloads are unaffected).  pcr_nn1 / pcr_icp do this themselves on first use. */
+PCR_API int pcr_cloud_prepare(pcr_ctx* ctx, pcr_cloud* cloud, const pcr_index* index);
 /* PointCloud.transform(T) in place (Registration/main.py:110), T row-major 4x4 */
 PCR_API int pcr_cloud_transform(pcr_ctx* ctx, pcr_cloud* cloud, const double T[16]);
 
@@ -182,6 +185,8 @@ PCR_API int pcr_timer_stop_ms(pcr_ctx* ctx, double* ms_out);
 /* Per-kernel HIP-event profile of the ICP pass (adds one event sync per pass while on).
  * slots: 0 = search phase 1 (grid) / MFMA sweep (brute), 1 = search phase 2 (grid) / merge (brute),
  *        2 = accumulate, 3 = reduce.  ms_out[4] = summed milliseconds, *passes_out = passes profiled. */
+/* diagnostics: per-block {cycles, work} stamps of the last grid search stage kernels (PCR_DEBUG_STAMPS=1) */
+PCR_API int pcr_debug_read(pcr_ctx* ctx, uint64_t* out, int64_t n_words);
 PCR_API int pcr_profile_enable(pcr_ctx* ctx, int on);
 PCR_API int pcr_profile_read(pcr_ctx* ctx, double ms_out[4], int* passes_out);
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "pcr_cloud_size": (C.c_int64, [_vp]),
     "pcr_cloud_free": (C.c_int, [_vp, _vp]),
     "pcr_cloud_transform": (C.c_int, [_vp, _vp, _dp]),
+    "pcr_cloud_prepare": (C.c_int, [_vp, _vp, _vp]),
     "pcr_index_build": (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.POINTER(_vp)]),
     "pcr_index_free": (C.c_int, [_vp, _vp]),
     "pcr_index_kind": (C.c_int, [_vp]),
@@ -103,6 +104,7 @@ SIGNATURES = {
     "pcr_voxel_filter": (C.c_int, [_vp, _dp, C.c_int64, C.c_double, C.c_int, C.c_uint64, _dp, _lp]),
     "pcr_voxel_filter_cloud": (C.c_int, [_vp, _vp, C.c_double, C.c_int, C.c_uint64, C.POINTER(_vp)]),
     "pcr_iss": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _ip, _ip, C.POINTER(C.c_int)]),
+    "pcr_debug_read": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int64]),
     "pcr_profile_enable": (C.c_int, [_vp, C.c_int]),
     "pcr_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "pcr_timer_start": (C.c_int, [_vp]),

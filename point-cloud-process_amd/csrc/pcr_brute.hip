@@ -44,6 +44,13 @@ __global__ void brute_prep_kernel(const pcr_pt* __restrict__ pts, long long n, l
     mfma_a[g] = v;
 }
 
+__global__ void brute_unpermute_kernel(const pcr_pt* __restrict__ in, long long n, pcr_pt* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pcr_pt p = in[i];
+    out[p.id] = p;
+}
+
 struct brute_cand {  // per (target split, query): best candidate of that split
     double d2;
     int id;
@@ -237,7 +244,8 @@ int pcr_brute_build(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_index* idx) {
     int rc;
     if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 64 * idx->n_tiles, (void**)&idx->mfma_a))) return rc;
     if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&idx->plain))) return rc;
-    PCR_HIP(ctx, hipMemcpyAsync(idx->plain, tgt->d, sizeof(pcr_pt) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    // row order (record id == position), whatever order the cloud currently has on the device
+    hipLaunchKernelGGL(brute_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)tgt->d, n, idx->plain);
     const long long threads = idx->n_tiles * 64;
     hipLaunchKernelGGL(brute_prep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)idx->plain, n,
                        (long long)idx->n_tiles, idx->view.origin[0], idx->view.origin[1], idx->view.origin[2], idx->mfma_a);

@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "pcr_internal.h"
 
 extern "C" {
@@ -52,6 +53,10 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
     }
     if (hipMalloc((void**)&c->d_counters, 4096) != hipSuccess) { delete c; return PCR_E_NOMEM; }
     hipMemsetAsync(c->d_counters, 0, 4096, c->stream);
+    if (getenv("PCR_DEBUG_STAMPS")) {
+        hipMalloc((void**)&c->d_debug, sizeof(unsigned long long) << 20);
+        hipMemsetAsync(c->d_debug, 0, sizeof(unsigned long long) << 20, c->stream);
+    }
     *out = c;
     return PCR_OK;
 }
@@ -86,6 +91,13 @@ int pcr_ctx_device_info(pcr_ctx* c, char* name256, int* cu, int64_t* hbm) {
     if (name256) { strncpy(name256, c->name, 255); name256[255] = 0; }
     if (cu) *cu = c->cu_count;
     if (hbm) *hbm = c->hbm_bytes;
+    return PCR_OK;
+}
+
+int pcr_debug_read(pcr_ctx* c, uint64_t* out, int64_t n) {
+    if (!c || !out || !c->d_debug || n > (1 << 20)) return PCR_E_INVALID;
+    PCR_HIP(c, hipStreamSynchronize(c->stream));
+    PCR_HIP(c, hipMemcpy(out, c->d_debug, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
     return PCR_OK;
 }
 
@@ -224,9 +236,10 @@ __global__ void pack_xyz_kernel(const pcr_pt* __restrict__ in, long long n, doub
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     pcr_pt p = in[i];
-    out[3 * i + 0] = p.x;
-    out[3 * i + 1] = p.y;
-    out[3 * i + 2] = p.z;
+    // records may have been reordered on the device (Morton sort); id is the caller's row
+    out[3 * p.id + 0] = p.x;
+    out[3 * p.id + 1] = p.y;
+    out[3 * p.id + 2] = p.z;
 }
 
 // p' = R p + t, evaluated as ((r0*x + r1*y) + r2*z) + t with no FMA contraction.

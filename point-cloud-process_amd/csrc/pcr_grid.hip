@@ -84,14 +84,18 @@ struct pcr_tables {
     unsigned int mask[PCR_MAX_LEVELS];
 };
 
+// buckets of 4 slots, filled from slot 0; mask = number of buckets - 1
 __device__ static inline unsigned int slot_find_or_insert(pcr_cell_slot* tab, unsigned int mask, unsigned long long key, unsigned int h) {
-    h &= mask;
+    unsigned int b = h & mask;
     for (unsigned int probe = 0; probe <= mask; ++probe) {
-        unsigned long long old = atomicCAS(&tab[h].key, PCR_EMPTY_KEY, key);
-        if (old == PCR_EMPTY_KEY || old == key) return h;
-        h = (h + 1) & mask;
+        for (unsigned int k = 0; k < 4; ++k) {
+            const unsigned int slot = b * 4 + k;
+            unsigned long long old = atomicCAS(&tab[slot].key, PCR_EMPTY_KEY, key);
+            if (old == PCR_EMPTY_KEY || old == key) return slot;
+        }
+        b = (b + 1) & mask;
     }
-    return 0xffffffffu;  // table full: cannot happen at load factor <= 0.5
+    return 0xffffffffu;  // table full: cannot happen at load factor <= 0.25
 }
 
 __global__ void insert_cells_kernel(const unsigned long long* __restrict__ keys, long long n, int levels, pcr_tables tabs) {
@@ -108,7 +112,7 @@ __global__ void insert_cells_kernel(const unsigned long long* __restrict__ keys,
             // table key = packed level-l cell coordinates (cheap to form at query time)
             const unsigned int X = compact21(ck), Y = compact21(ck >> 1), Z = compact21(ck >> 2);
             const unsigned long long pk = (unsigned long long)X | ((unsigned long long)Y << 21) | ((unsigned long long)Z << 42);
-            unsigned int h = slot_find_or_insert(tabs.t[l], tabs.mask[l], pk, (X * 73856093u) ^ (Y * 19349663u) ^ (Z * 83492791u));
+            unsigned int h = slot_find_or_insert(tabs.t[l], tabs.mask[l], pk, cell_hash(X, Y, Z));
             if (h != 0xffffffffu) {
                 if (start) tabs.t[l][h].start = (unsigned int)i;
                 if (end) tabs.t[l][h].end = (unsigned int)(i + 1);
@@ -203,13 +207,13 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
     pcr_tables tabs;
     memset(&tabs, 0, sizeof(tabs));
     for (int l = 0; l < levels; ++l) {
-        unsigned int cap = (unsigned int)next_pow2(h_counts[l] * 2 + 2);
+        unsigned int cap = (unsigned int)next_pow2(h_counts[l] * 4 + 4);  // slots; load factor <= 0.25
         if (cap < 16) cap = 16;
         idx->caps[l] = cap;
         if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_cell_slot) * cap, (void**)&idx->tables[l]))) return rc;
         PCR_HIP(ctx, hipMemsetAsync(idx->tables[l], 0xff, sizeof(pcr_cell_slot) * cap, ctx->stream));
         tabs.t[l] = idx->tables[l];
-        tabs.mask[l] = cap - 1;
+        tabs.mask[l] = cap / 4 - 1;  // buckets of 4 slots
     }
     hipLaunchKernelGGL(insert_cells_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const unsigned long long*)d_keys2, n, levels, tabs);
     PCR_HIP(ctx, hipGetLastError());
@@ -232,8 +236,48 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
     }
     for (int l = 0; l < levels; ++l) {
         v.table[l] = idx->tables[l];
-        v.mask[l] = idx->caps[l] - 1;
+        v.mask[l] = idx->caps[l] / 4 - 1;  // buckets of 4 slots
     }
+    return PCR_OK;
+}
+
+int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell) {
+    if (c->morton_sorted || c->n < 2) { c->morton_sorted = true; return PCR_OK; }
+    const long long n = c->n;
+    const int block = 256;
+    const int grid_n = (int)((n + block - 1) / block);
+    double lo[3], hi[3];
+    int rc = pcr_bbox(ctx, c->d, n, lo, hi);
+    if (rc) return rc;
+    const double emax = fmax(hi[0] - lo[0], fmax(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(cell > 0)) cell = emax > 0 ? emax / 1024.0 : 1.0;
+    if (cell < emax / 262144.0) cell = emax / 262144.0;
+    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+    unsigned int *d_vals = nullptr, *d_vals2 = nullptr;
+    pcr_pt* d_out = nullptr;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys2))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals2))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&d_out))) return rc;
+    hipLaunchKernelGGL(morton_keys_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, n, lo[0], lo[1], lo[2],
+                       1.0 / cell, d_keys, d_vals);
+    size_t temp_bytes = 0;
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, 63, ctx->stream));
+    void* d_temp = nullptr;
+    if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, 63, ctx->stream));
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, (const unsigned int*)d_vals2, n,
+                       d_out);
+    PCR_HIP(ctx, hipGetLastError());
+    pcr_dev_free(ctx, d_temp, temp_bytes);
+    pcr_dev_free(ctx, d_keys, sizeof(unsigned long long) * n);
+    pcr_dev_free(ctx, d_keys2, sizeof(unsigned long long) * n);
+    pcr_dev_free(ctx, d_vals, sizeof(unsigned int) * n);
+    pcr_dev_free(ctx, d_vals2, sizeof(unsigned int) * n);
+    pcr_dev_free(ctx, c->d, sizeof(pcr_pt) * n);
+    c->d = d_out;
+    c->morton_sorted = true;
     return PCR_OK;
 }
 

@@ -58,7 +58,7 @@ int pcr_nn1(pcr_ctx* ctx, const pcr_index* index, const pcr_cloud* queries, cons
     if ((rc = pcr_dev_alloc(ctx, sizeof(double) * nq, (void**)&d_d2))) return rc;
     pcr_xform x;
     if (T) pcr_xform_from_T(T, &x);
-    if (index->kind == PCR_INDEX_GRID) rc = pcr_grid_nn1(ctx, index, queries->d, nq, T ? &x : nullptr, max_d2, d_idx, d_d2);
+    if (index->kind == PCR_INDEX_GRID) rc = pcr_grid_nn1(ctx, index, const_cast<pcr_cloud*>(queries), T ? &x : nullptr, max_d2, d_idx, d_d2);
     else rc = pcr_brute_nn1(ctx, index, queries->d, nq, T ? &x : nullptr, max_d2, d_idx, d_d2);
     if (rc == PCR_OK) {
         PCR_HIP(ctx, hipMemcpyAsync(idx_out, d_idx, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
@@ -84,10 +84,10 @@ void pcr_icp_default_params(pcr_icp_params* p) {
 
 }  // extern "C"
 
-static int icp_pass(pcr_ctx* ctx, const pcr_index* index, pcr_pt* q, int64_t nq, const pcr_xform* x, double max_d2, int write_back,
+static int icp_pass(pcr_ctx* ctx, const pcr_index* index, pcr_cloud* qc, const pcr_xform* x, double max_d2, int write_back,
                     double* d_mom) {
-    if (index->kind == PCR_INDEX_GRID) return pcr_grid_icp_pass(ctx, index, q, nq, x, max_d2, write_back, d_mom);
-    return pcr_brute_icp_pass(ctx, index, q, nq, x, max_d2, write_back, d_mom);
+    if (index->kind == PCR_INDEX_GRID) return pcr_grid_icp_pass(ctx, index, qc, x, max_d2, write_back, d_mom);
+    return pcr_brute_icp_pass(ctx, index, qc->d, qc->n, x, max_d2, write_back, d_mom);
 }
 
 static void T_from_Rt(const double R[9], const double t[3], double T[16]) {
@@ -121,7 +121,7 @@ int pcr_icp_moments(pcr_ctx* ctx, const pcr_cloud* source, const pcr_index* inde
     double* d_mom = nullptr;
     int rc = pcr_dev_alloc(ctx, sizeof(double) * PCR_NMOM, (void**)&d_mom);
     if (rc) return rc;
-    rc = icp_pass(ctx, index, source->d, source->n, &x, max_d2, 0, d_mom);
+    rc = icp_pass(ctx, index, const_cast<pcr_cloud*>(source), &x, max_d2, 0, d_mom);
     if (rc == PCR_OK) {
         PCR_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_mom, sizeof(double) * PCR_NMOM, hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -168,7 +168,7 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
         pcr_xform_from_T(T_cur, &x);
         // main.py:110 / icp_template.py:195: the source is transformed in place, fused into the pass
         PCR_HIP(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-        rc = icp_pass(ctx, index, source->d, source->n, &x, params->max_d2, 1, d_mom);
+        rc = icp_pass(ctx, index, source, &x, params->max_d2, 1, d_mom);
         if (rc) break;
         PCR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
         PCR_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_mom, sizeof(double) * PCR_NMOM, hipMemcpyDeviceToHost, ctx->stream));
@@ -294,3 +294,10 @@ int pcr_homo2tq(const double T[16], double out[7]) {
 }
 
 }  // extern "C"
+
+extern "C" int pcr_cloud_prepare(pcr_ctx* ctx, pcr_cloud* cloud, const pcr_index* index) {
+    if (!ctx || !cloud || !index) return PCR_E_INVALID;
+    hipSetDevice(ctx->device);
+    if (index->kind != PCR_INDEX_GRID) return PCR_OK;  // the brute-force sweep does not care about record order
+    return pcr_cloud_morton_sort(ctx, cloud, index->cell);
+}

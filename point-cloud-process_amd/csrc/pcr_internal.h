@@ -47,6 +47,7 @@ struct pcr_grid_view {
 struct pcr_cloud {
     pcr_pt* d = nullptr;
     int64_t n = 0;
+    bool morton_sorted = false;  // records reordered for spatial locality (id keeps the caller's row)
 };
 
 struct pcr_index {
@@ -80,6 +81,7 @@ struct pcr_ctx {
     double* d_partials = nullptr;
     size_t d_partials_bytes = 0;
     unsigned int* d_counters = nullptr;  // small zeroed scratch (tickets, flags)
+    unsigned long long* d_debug = nullptr;  // diagnostics stamps (PCR_DEBUG_STAMPS=1), 1 Mi words
     // optional per-kernel profile of the ICP pass
     bool profile = false;
     hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -110,13 +112,16 @@ PCR_HIDDEN void pcr_prof_finish(pcr_ctx* ctx);
 // grid (pcr_grid.hip)
 PCR_HIDDEN int pcr_bbox(pcr_ctx* ctx, const pcr_pt* pts, long long n, double lo[3], double hi[3]);
 PCR_HIDDEN int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* idx);
+// Reorder a cloud's records along a Morton curve (cell = curve resolution); rigid transforms keep the locality.
+PCR_HIDDEN int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell);
 PCR_HIDDEN void pcr_grid_free(pcr_ctx* ctx, pcr_index* idx);
-PCR_HIDDEN int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, const pcr_pt* q, int64_t nq, const pcr_xform* x,
-                            double max_d2, int32_t* d_idx, double* d_d2);
+// (the query cloud may be re-ordered on the device: record ids keep the caller's rows)
+PCR_HIDDEN int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xform* x, double max_d2, int32_t* d_idx,
+                            double* d_d2);
 // One fused association+accumulate pass.  If write_back, q[i] <- x(q[i]) (in-place transform).
 // d_moments receives 20 doubles: 18 moments + sum d2 + (unused).
-PCR_HIDDEN int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, const pcr_xform* x,
-                                 double max_d2, int write_back, double* d_moments);
+PCR_HIDDEN int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xform* x, double max_d2,
+                                 int write_back, double* d_moments);
 // brute (pcr_brute.hip)
 PCR_HIDDEN int pcr_brute_build(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_index* idx);
 PCR_HIDDEN void pcr_brute_free(pcr_ctx* ctx, pcr_index* idx);

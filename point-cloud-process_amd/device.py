@@ -124,6 +124,11 @@ class DeviceCloud:
         L.check(L.lib().pcr_cloud_transform(self.ctx.handle, self.handle, L.dptr(T)), self.ctx.handle)
         return self
 
+    def prepare(self, index):
+        """Lay the records out for queries against `index` (done lazily otherwise)."""
+        L.check(L.lib().pcr_cloud_prepare(self.ctx.handle, self.handle, index.handle), self.ctx.handle)
+        return self
+
     def free(self):
         if self._h:
             L.lib().pcr_cloud_free(self.ctx.handle, self._h)

@@ -1,0 +1,30 @@
+"""Distribution of per-tile cycles / staged points (PCR_DEBUG_STAMPS=1)."""
+import ctypes as C, importlib, os, sys
+import numpy as np
+os.environ["PCR_DEBUG_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pcp = importlib.import_module("point-cloud-process_amd")
+L = pcp._lib
+src, tgt, Tt = pcp.synthetic.perturbed_pair(120000, seed=0)
+cell = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
+ctx = pcp.default_context()
+index = pcp.TargetIndex(tgt, kind="grid", cell=cell)
+sd = pcp.DeviceCloud.upload(src).prepare(index)
+r = pcp.icp_device(sd, index, np.eye(4), mode="total", max_iter=3, r_thres=-1, t_thres=-1, min_iter=3)
+nb = (120000 + 63) // 64
+buf = np.zeros((1 << 16) + nb * 8, dtype=np.uint64)
+L.check(L.lib().pcr_debug_read(ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size))
+ph = buf[(1 << 16):].reshape(nb, 8)[:, :5].astype(np.float64)
+b = buf[: nb * 4].reshape(nb, 4)
+cyc = b[:, 0].astype(np.float64); P = b[:, 1].astype(np.float64); lvl = (b[:, 2] >> np.uint64(32)).astype(int) - 1; ncell = (b[:, 2] & np.uint64(0xffffffff)).astype(int)
+c0 = (b[:, 3] >> np.uint64(40)).astype(int); c1 = ((b[:, 3] >> np.uint64(20)) & np.uint64(0xfffff)).astype(int); c2 = (b[:, 3] & np.uint64(0xfffff)).astype(int)
+print("cell", index.cell, "blocks", nb)
+print("cycles(100MHz ticks?) pct 50/90/99/max", np.percentile(cyc, [50, 90, 99, 100]), "sum", cyc.sum())
+print("P pct 50/90/99/max", np.percentile(P, [50, 90, 99, 100]), "mean", P.mean())
+print("levels", np.bincount(lvl + 1), "ncell mean", ncell.mean())
+print("lists ring1/ring2/hard totals", c0.sum(), c1.sum(), c2.sum(), "max per block", c0.max(), c1.max(), c2.max())
+o = np.argsort(-cyc)[:8]
+print("slowest blocks:", [(int(cyc[i]), int(P[i]), int(lvl[i]), int(ncell[i])) for i in o])
+print("corr cycles~P", np.corrcoef(cyc, P)[0, 1])
+print("phase stamps (cycles since start) median: load+box %.0f | lookups %.0f | scan %.0f | staged(last round) %.0f | eval done %.0f | end %.0f" % (*np.median(ph, axis=0), np.median(cyc)))
+print("phase stamps p90:", np.percentile(ph, 90, axis=0))
