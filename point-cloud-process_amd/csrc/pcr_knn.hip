@@ -1,0 +1,300 @@
+// Batched k-NN and radius queries on the voxel-hash grid: the device side of
+// kdtree_knn_search / octree_knn_search (Kdtree_Octree/lesson2/kdtree.py:141-172,
+// octree.py:262-306) and kdtree_radius_search / octree_radius_search(_fast)
+// (kdtree.py:176-208, octree.py:166-259).  One wave per query walks the nested cell
+// hierarchy top-down, pruning cells whose box is farther than the current bound.
+//   k-NN   k rounds; round r finds the nearest point that is lexicographically greater in
+//          (d2, index) than the result of round r-1 -- ascending distances, ties by index,
+//          exactly the order of a stable sort of all distances.
+//   radius bound fixed to r; a count pass, then a fill pass into caller-provided offsets.
+// Distances are reported as sqrt((dx*dx+dy*dy)+dz*dz) in binary64 (result_set.py stores
+// np.linalg.norm values).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <vector>
+#include "pcr_grid_dev.h"
+
+constexpr int KN_STACK = 192;
+constexpr unsigned int KN_SCAN_T = 128;
+
+struct kn_entry {
+    unsigned int start, end;
+    unsigned int x, y, z;
+    int level;
+};
+
+__device__ static inline double kn_sq_pos(double v) {
+    v = fmax(v, 0.0);
+    return v * v;
+}
+
+__device__ static inline double kn_box_dist2(const pcr_grid_view& gv, int level, double cell, unsigned int X, unsigned int Y, unsigned int Z,
+                                             double ax, double ay, double az) {
+    const int bl = (int)(PCR_COORD_BIAS >> (2 * level));
+    const double slack = cell * 1e-9;
+    const double x0 = gv.lo[0] + (double)((int)X - bl) * cell;
+    const double y0 = gv.lo[1] + (double)((int)Y - bl) * cell;
+    const double z0 = gv.lo[2] + (double)((int)Z - bl) * cell;
+    const double dx = kn_sq_pos(fmax(x0 - ax, ax - (x0 + cell)) - slack);
+    const double dy = kn_sq_pos(fmax(y0 - ay, ay - (y0 + cell)) - slack);
+    const double dz = kn_sq_pos(fmax(z0 - az, az - (z0 + cell)) - slack);
+    return (dx + dy) + dz;
+}
+
+// Pruned descent from the root cells.  `scan(start, end, bound2)` is called (wave-uniformly) for
+// every cell that has to be read; it may lower bound2.
+template <class Scan>
+__device__ static inline void kn_descend(const pcr_grid_view& gv, double ax, double ay, double az, double& bound2, kn_entry* stack, int lane,
+                                         Scan& scan) {
+    const int top = gv.levels - 1;
+    int sp = 0;
+    {
+        const double cell = gv.cell0 * (double)(1ll << (2 * top));
+        const int b0 = (int)(PCR_COORD_BIAS >> (2 * top));
+        const unsigned int X = b0 + (lane & 1), Y = b0 + ((lane >> 1) & 1), Z = b0 + ((lane >> 2) & 1);
+        unsigned int s = 0, e = 0;
+        bool valid = lane < 8;
+        double bdist = 0.0;
+        if (valid) {
+            bdist = kn_box_dist2(gv, top, cell, X, Y, Z, ax, ay, az);
+            valid = bdist <= bound2 && lookup_cell(gv.table[top], gv.mask[top], X, Y, Z, &s, &e);
+        }
+        const unsigned long long m_far = __ballot(valid && bdist > 0.0), m_near = __ballot(valid && !(bdist > 0.0));
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int slot = -1;
+        if (valid && bdist > 0.0) slot = __popcll(m_far & below);
+        else if (valid) slot = __popcll(m_far) + __popcll(m_near & below);
+        if (slot >= 0) stack[slot] = kn_entry{s, e, X, Y, Z, top};
+        sp = __popcll(m_far) + __popcll(m_near);
+    }
+    while (sp > 0) {
+        --sp;
+        const kn_entry en = stack[sp];
+        const double cell = gv.cell0 * (double)(1ll << (2 * en.level));
+        if (kn_box_dist2(gv, en.level, cell, en.x, en.y, en.z, ax, ay, az) > bound2) continue;
+        const unsigned int cnt = en.end - en.start;
+        const bool room = sp + 64 <= KN_STACK;
+        if (en.level == 0 || cnt <= KN_SCAN_T || !room) {
+            scan(en.start, en.end, bound2);
+        } else {
+            const int cl = en.level - 1;
+            const unsigned int X = en.x * 4u + (lane & 3), Y = en.y * 4u + ((lane >> 2) & 3), Z = en.z * 4u + (lane >> 4);
+            const double bdist = kn_box_dist2(gv, cl, cell * 0.25, X, Y, Z, ax, ay, az);
+            unsigned int s = 0, e = 0;
+            const bool valid = bdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], X, Y, Z, &s, &e);
+            const unsigned long long m_far = __ballot(valid && bdist > 0.0), m_near = __ballot(valid && !(bdist > 0.0));
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int slot = -1;
+            if (valid && bdist > 0.0) slot = __popcll(m_far & below);
+            else if (valid) slot = __popcll(m_far) + __popcll(m_near & below);
+            if (slot >= 0) stack[sp + slot] = kn_entry{s, e, X, Y, Z, cl};
+            sp += __popcll(m_far) + __popcll(m_near);
+        }
+    }
+}
+
+struct knn_scan {
+    const pcr_pt* pts;
+    double ax, ay, az;
+    double floor_d2;     // results must be lexicographically greater than (floor_d2, floor_id)
+    long long floor_id;
+    double bd2;
+    long long bid;
+    int lane;
+    __device__ void operator()(unsigned int s, unsigned int e, double& bound2) {
+        for (unsigned int j = s + lane; j < e; j += 64) {
+            const pcr_pt b = pts[j];
+            const double d2 = dist2(ax, ay, az, b);
+            const bool above = d2 > floor_d2 || (d2 == floor_d2 && b.id > floor_id);
+            if (above && better(d2, b.id, bd2, bid)) { bd2 = d2; bid = b.id; }
+        }
+        double m = bd2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+        bound2 = fmin(bound2, m);
+    }
+};
+
+__global__ void __launch_bounds__(256)
+knn_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq, int k, int* __restrict__ idx_out, double* __restrict__ dist_out) {
+    __shared__ kn_entry s_stack[4][KN_STACK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long qi = (long long)blockIdx.x * 4 + wave;
+    if (qi >= nq) return;
+    knn_scan sc;
+    sc.pts = gv.pts;
+    sc.ax = queries[3 * qi];
+    sc.ay = queries[3 * qi + 1];
+    sc.az = queries[3 * qi + 2];
+    sc.lane = lane;
+    sc.floor_d2 = -1.0;
+    sc.floor_id = -1;
+    for (int r = 0; r < k; ++r) {
+        sc.bd2 = DBL_MAX;
+        sc.bid = 0x7fffffffffffffffll;
+        double bound2 = DBL_MAX;
+        kn_descend(gv, sc.ax, sc.ay, sc.az, bound2, s_stack[wave], lane, sc);
+        double bd2 = sc.bd2;
+        long long bid = sc.bid;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od2 = __shfl_xor(bd2, off, 64);
+            const long long oid = __shfl_xor(bid, off, 64);
+            if (better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; }
+        }
+        const bool found = bd2 < DBL_MAX;
+        if (lane == 0) {
+            // unfilled slots keep KNNResultSet's initial (1e10, 0) (result_set.py:19-22)
+            idx_out[qi * k + r] = found ? (int)bid : 0;
+            dist_out[qi * k + r] = found ? sqrt(bd2) : 1e10;
+        }
+        if (!found) {
+            if (lane == 0)
+                for (int rr = r + 1; rr < k; ++rr) { idx_out[qi * k + rr] = 0; dist_out[qi * k + rr] = 1e10; }
+            break;
+        }
+        sc.floor_d2 = bd2;
+        sc.floor_id = bid;
+    }
+}
+
+struct radius_scan {
+    const pcr_pt* pts;
+    double ax, ay, az, radius;
+    int lane;
+    unsigned int count;        // wave-uniform running count
+    int* idx_out;              // null in the count pass
+    double* dist_out;
+    long long base;
+    __device__ void operator()(unsigned int s, unsigned int e, double& bound2) {
+        (void)bound2;
+        for (unsigned int j0 = s; j0 < e; j0 += 64) {
+            const unsigned int j = j0 + lane;
+            bool hit = false;
+            double d = 0;
+            long long id = 0;
+            if (j < e) {
+                const pcr_pt b = pts[j];
+                d = sqrt(dist2(ax, ay, az, b));
+                hit = !(d > radius);  // RadiusNNResultSet.add_point rejects dist > radius (result_set.py:80)
+                id = b.id;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (idx_out && hit) {
+                const unsigned int k = count + __popcll(m & ((1ull << lane) - 1ull));
+                idx_out[base + k] = (int)id;
+                dist_out[base + k] = d;
+            }
+            count += __popcll(m);
+        }
+    }
+};
+
+__global__ void __launch_bounds__(256)
+radius_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq, double radius, long long* __restrict__ counts_out,
+              const long long* __restrict__ offsets, int* __restrict__ idx_out, double* __restrict__ dist_out) {
+    __shared__ kn_entry s_stack[4][KN_STACK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long qi = (long long)blockIdx.x * 4 + wave;
+    if (qi >= nq) return;
+    radius_scan sc;
+    sc.pts = gv.pts;
+    sc.ax = queries[3 * qi];
+    sc.ay = queries[3 * qi + 1];
+    sc.az = queries[3 * qi + 2];
+    sc.radius = radius;
+    sc.lane = lane;
+    sc.count = 0;
+    sc.idx_out = offsets ? idx_out : nullptr;
+    sc.dist_out = dist_out;
+    sc.base = offsets ? offsets[qi] : 0;
+    double bound2 = radius * radius * (1.0 + 1e-12);  // conservative cell pruning; membership is tested on sqrt(d2)
+    kn_descend(gv, sc.ax, sc.ay, sc.az, bound2, s_stack[wave], lane, sc);
+    if (lane == 0 && !offsets) counts_out[qi] = sc.count;
+}
+
+extern "C" {
+
+int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t q, int k, int32_t* idx_out, double* dist_out) {
+    if (!ctx || !index || !queries || !idx_out || !dist_out || k <= 0) return PCR_E_INVALID;
+    if (q <= 0) return PCR_OK;
+    if (index->kind != PCR_INDEX_GRID) return PCR_E_UNSUPPORTED;
+    hipSetDevice(ctx->device);
+    double* d_q = nullptr;
+    int* d_idx = nullptr;
+    double* d_dist = nullptr;
+    int rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 3 * q, (void**)&d_q))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(int) * q * k, (void**)&d_idx))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * q * k, (void**)&d_dist))) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(d_q, queries, sizeof(double) * 3 * q, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(knn_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, k,
+                       d_idx, d_dist);
+    PCR_HIP(ctx, hipGetLastError());
+    PCR_HIP(ctx, hipMemcpyAsync(idx_out, d_idx, sizeof(int) * q * k, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipMemcpyAsync(dist_out, d_dist, sizeof(double) * q * k, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pcr_dev_free(ctx, d_q, sizeof(double) * 3 * q);
+    pcr_dev_free(ctx, d_idx, sizeof(int) * q * k);
+    pcr_dev_free(ctx, d_dist, sizeof(double) * q * k);
+    return PCR_OK;
+}
+
+int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t q, double radius, int64_t* counts_out,
+               const int64_t* offsets, int32_t* idx_out, double* dist_out) {
+    if (!ctx || !index || !queries || !(radius >= 0)) return PCR_E_INVALID;
+    if (!offsets && !counts_out) return PCR_E_INVALID;
+    if (offsets && (!idx_out || !dist_out)) return PCR_E_INVALID;
+    if (q <= 0) return PCR_OK;
+    if (index->kind != PCR_INDEX_GRID) return PCR_E_UNSUPPORTED;
+    hipSetDevice(ctx->device);
+    double* d_q = nullptr;
+    long long* d_counts = nullptr;
+    long long* d_offs = nullptr;
+    int* d_idx = nullptr;
+    double* d_dist = nullptr;
+    int rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 3 * q, (void**)&d_q))) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(d_q, queries, sizeof(double) * 3 * q, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned grid = (unsigned)((q + 3) / 4);
+    if (!offsets) {
+        if ((rc = pcr_dev_alloc(ctx, sizeof(long long) * q, (void**)&d_counts))) return rc;
+        hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, radius,
+                           d_counts, (const long long*)nullptr, (int*)nullptr, (double*)nullptr);
+        PCR_HIP(ctx, hipGetLastError());
+        PCR_HIP(ctx, hipMemcpyAsync(counts_out, d_counts, sizeof(long long) * q, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        pcr_dev_free(ctx, d_counts, sizeof(long long) * q);
+    } else {
+        const int64_t total = offsets[q];
+        if ((rc = pcr_dev_alloc(ctx, sizeof(long long) * (q + 1), (void**)&d_offs))) return rc;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(int) * (total + 1), (void**)&d_idx))) return rc;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(double) * (total + 1), (void**)&d_dist))) return rc;
+        PCR_HIP(ctx, hipMemcpyAsync(d_offs, offsets, sizeof(long long) * (q + 1), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, radius,
+                           (long long*)nullptr, (const long long*)d_offs, d_idx, d_dist);
+        PCR_HIP(ctx, hipGetLastError());
+        if (total > 0) {
+            PCR_HIP(ctx, hipMemcpyAsync(idx_out, d_idx, sizeof(int) * total, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipMemcpyAsync(dist_out, d_dist, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // ascending distance (ties by index) inside every query's segment
+        std::vector<std::pair<double, int>> tmp;
+        for (int64_t i = 0; i < q; ++i) {
+            const int64_t s = offsets[i], e = offsets[i + 1];
+            tmp.resize((size_t)(e - s));
+            for (int64_t j = s; j < e; ++j) tmp[(size_t)(j - s)] = {dist_out[j], idx_out[j]};
+            std::sort(tmp.begin(), tmp.end());
+            for (int64_t j = s; j < e; ++j) { dist_out[j] = tmp[(size_t)(j - s)].first; idx_out[j] = tmp[(size_t)(j - s)].second; }
+        }
+        pcr_dev_free(ctx, d_offs, sizeof(long long) * (q + 1));
+        pcr_dev_free(ctx, d_idx, sizeof(int) * (total + 1));
+        pcr_dev_free(ctx, d_dist, sizeof(double) * (total + 1));
+    }
+    pcr_dev_free(ctx, d_q, sizeof(double) * 3 * q);
+    return PCR_OK;
+}
+
+}  // extern "C"
