@@ -1,0 +1,124 @@
+"""Batched scan-pair registration sharded across the GPUs of one node (BASELINE config 4).
+
+The reference loops over pairs serially (Registration/main.py:190-216); pairs are independent, so
+they are dealt to ranks in contiguous blocks (one process per GPU), every rank registers its own
+share -- optionally several pairs in flight on separate HIP streams to hide the per-iteration host
+round trip -- and the fixed-size result records are exchanged with ONE all_gather (RCCL over xGMI
+on GPUs, gloo in the CPU tests).  There is no per-iteration communication and a single pair is
+never split.
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+RECORD = 24  # doubles per result record: pair id, 16 x T, iters, status, n_assoc, cost, mean_d2, 2 spare
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block partition: rank r gets [lo, hi); sizes differ by at most one."""
+    base, rem = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def pack_result(pair_id, res):
+    rec = np.zeros(RECORD)
+    rec[0] = pair_id
+    rec[1:17] = np.asarray(res["T"], dtype=np.float64).reshape(16)
+    rec[17] = res.get("iters", 0)
+    rec[18] = res.get("status", 0)
+    rec[19] = res.get("n_assoc", 0)
+    rec[20] = res.get("cost", 0.0)
+    rec[21] = res.get("mean_d2", 0.0)
+    return rec
+
+
+def unpack_results(table):
+    out = []
+    for rec in np.asarray(table).reshape(-1, RECORD):
+        out.append({"pair": int(rec[0]), "T": rec[1:17].reshape(4, 4).copy(), "iters": int(rec[17]), "status": int(rec[18]),
+                    "n_assoc": int(rec[19]), "cost": float(rec[20]), "mean_d2": float(rec[21])})
+    return out
+
+
+def gpu_register_fn(device=0, nn="grid", mode="compat", streams=1, **icp_kw):
+    """Default worker: ICP on `device` through libpcr (one Context = one HIP stream per worker thread)."""
+    from .device import Context, DeviceCloud, TargetIndex, icp_device
+
+    ctxs = [Context(device) for _ in range(max(1, int(streams)))]
+
+    def run(slot, src, tgt, T0):
+        ctx = ctxs[slot % len(ctxs)]
+        sd = DeviceCloud.upload(src, ctx)
+        index = TargetIndex(DeviceCloud.upload(tgt, ctx), kind=nn, ctx=ctx)
+        try:
+            return icp_device(sd, index, np.eye(4) if T0 is None else T0, mode=mode, **icp_kw)
+        finally:
+            sd.free()
+            index.free()
+
+    run.streams = len(ctxs)
+    return run
+
+
+def register_batch(pairs, register_fn=None, group=None, device=None, streams=2, **kw):
+    """Register ``pairs`` = sequence of (src (N,3+), tgt (M,3+), T0 or None).
+
+    Without torch.distributed (or world size 1) everything runs on this process's GPU.  Inside an
+    initialised process group every rank must call this with the SAME ``pairs`` list (or at least a
+    list of the same length: only the local share is touched); each rank gets the full, ordered
+    result list back.
+    """
+    dist = None
+    rank, world = 0, 1
+    try:
+        import torch.distributed as dist  # noqa: PLC0415
+
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            dist = None
+    except Exception:
+        dist = None
+    n = len(pairs)
+    lo, hi = shard_range(n, rank, world)
+    if register_fn is None:
+        if device is None:
+            import os
+
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        register_fn = gpu_register_fn(device=device, streams=streams, **kw)
+    workers = int(getattr(register_fn, "streams", 1))
+    local = np.zeros((hi - lo, RECORD))
+
+    def one(i):
+        src, tgt, T0 = pairs[i]
+        res = register_fn((i - lo) % workers, src, tgt, T0)
+        local[i - lo] = pack_result(i, res)
+
+    if workers > 1 and hi - lo > 1:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(one, range(lo, hi)))
+    else:
+        for i in range(lo, hi):
+            one(i)
+    if dist is None or world == 1:
+        return unpack_results(local)
+    # one collective: fixed-size records, padded to the largest share
+    import torch
+
+    share = (n + world - 1) // world
+    use_cuda = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    buf = torch.full((share, RECORD), -1.0, dtype=torch.float64, device=dev)
+    if hi > lo:
+        buf[: hi - lo] = torch.from_numpy(local).to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    table = torch.cat(gathered).cpu().numpy()
+    table = table[table[:, 0] >= 0]
+    table = table[np.argsort(table[:, 0], kind="stable")]
+    return unpack_results(table)

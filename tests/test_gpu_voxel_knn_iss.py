@@ -122,3 +122,17 @@ def test_iss_matches_cpu_restatement(pcp, oracle, syn):
     assert np.allclose(lam, olam, rtol=1e-9, atol=1e-15)
     assert kp == okp
     assert len(kp) <= 21
+
+
+def test_register_batch_single_gpu_streams(pcp, oracle, syn):
+    """BASELINE config 4 on one GPU: several pairs in flight on separate HIP streams, ordered results."""
+    pairs = []
+    for i in range(6):
+        s6, t6, _ = syn.registration_pair_6f(4000, seed=1000 + i)  # 6-float records like registration_dataset/*.bin
+        pairs.append((s6, t6, None))
+    res = pcp.register_batch(pairs, streams=3)
+    assert [r["pair"] for r in res] == list(range(6))
+    for (s6, t6, _), r in zip(pairs, res):
+        ref = oracle.icp_point2point(s6[:, :3], t6[:, :3], np.eye(4))
+        assert r["iters"] == ref["iters"]
+        assert np.linalg.norm(r["T"] - ref["T"]) < 1e-9

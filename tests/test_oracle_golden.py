@@ -75,3 +75,51 @@ def test_knn_radius_match_reference_trees(oracle):
                 for tree in ("kd", "oct", "octfast"):
                     assert np.array_equal(idx, g[f"{name}_{tree}_rad{rad}_q{qi}_idx"]), (name, tree, rad, qi)
                     assert np.allclose(dist, g[f"{name}_{tree}_rad{rad}_q{qi}_dist"], rtol=1e-14, atol=0)
+
+
+# ---------------------------------------------------------------- C oracle
+def _c_oracle():
+    import ctypes as C
+    import os
+
+    from tests.conftest import ROOT
+
+    path = os.path.join(ROOT, "oracle", "liboracle_c.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/liboracle_c.so not built (run __graft_entry__.build())")
+    return C.CDLL(path), C
+
+
+def test_c_oracle_against_reference_goldens(oracle):
+    lib, C = _c_oracle()
+    dp = C.POINTER(C.c_double)
+    g = load_golden("voxel_filter.npz")
+    for tag in g["cases"]:
+        tag = str(tag)
+        cname, leaf = tag.split("_leaf")
+        pts = np.ascontiguousarray(g[f"{cname}_in"], dtype=np.float64)
+        h = np.empty(len(pts))
+        D = np.empty(3)
+        lib.oc_voxel_keys(pts.ctypes.data_as(dp), C.c_int64(len(pts)), C.c_double(float(leaf)), h.ctypes.data_as(dp), D.ctypes.data_as(dp))
+        assert np.array_equal(h, g[f"{tag}_h"]) and np.array_equal(D, g[f"{tag}_D"]), tag
+    g = load_golden("icp_compat.npz")
+    for tag in g["cases"]:
+        tag = str(tag)
+        src = np.ascontiguousarray(g[f"{tag}_src"], dtype=np.float64)
+        tgt = np.ascontiguousarray(g[f"{tag}_tgt"], dtype=np.float64)
+        if len(src) * len(tgt) > 2e7:
+            continue  # exhaustive NN: keep the CPU suite short
+        T0 = np.ascontiguousarray(g[f"{tag}_T0"], dtype=np.float64)
+        T = np.zeros(16)
+        failed = C.c_int()
+        lib.oc_icp_point2point.restype = C.c_int
+        iters = lib.oc_icp_point2point(src.ctypes.data_as(dp), C.c_int64(len(src)), tgt.ctypes.data_as(dp), C.c_int64(len(tgt)),
+                                       T0.ctypes.data_as(dp), T.ctypes.data_as(dp), C.byref(failed))
+        assert iters == int(g[f"{tag}_iters"][0]) and failed.value == int(g[f"{tag}_failed"][0]), tag
+        assert np.linalg.norm(T.reshape(4, 4) - g[f"{tag}_T"]) < 1e-9, tag
+        assert np.abs(src - g[f"{tag}_src_after"]).max() < 1e-9, tag
+    p = load_golden("pose_utils.npz")
+    for T, tq in zip(p["T"], p["tq"]):
+        out = np.zeros(7)
+        lib.oc_homo2tq(np.ascontiguousarray(T).ctypes.data_as(dp), out.ctypes.data_as(dp))
+        assert np.allclose(out, tq, rtol=0, atol=1e-15)
