@@ -26,7 +26,8 @@
 #include "pcr_grid_dev.h"
 
 constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
-constexpr int T_MAXC = 512;                 // cells in a tile box
+constexpr int T_MAXC = 1024;                // cells in a tile box
+constexpr int T_CPT = T_MAXC / 256;         // cells looked up per thread
 constexpr int T_PMAX = 512;                 // points staged per round
 constexpr unsigned int T_PCAP = 4 * T_PMAX;   // tiles with more candidate points than this go per-query
 constexpr int SG = 8;                       // lanes per query in rings 1 and 2
@@ -170,10 +171,12 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         const int ncell = sm.ncell;
         const int d0 = sm.dims[0], d1 = sm.dims[1];
         const int lim = (int)(PCR_COORD_MAX >> (2 * level));
-        unsigned int my_cnt[2] = {0, 0};
+        // thread t looks up cells t, t+256, ... (independent 64-B bucket reads)
+        unsigned int my_cnt[T_CPT];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < T_CPT; ++r) {
             const int c = tid + r * 256;
+            my_cnt[r] = 0;
             if (c < ncell) {
                 const int ix = c % d0, iy = (c / d0) % d1, iz = c / (d0 * d1);
                 const int X = sm.box_lo[0] + ix, Y = sm.box_lo[1] + iy, Z = sm.box_lo[2] + iz;
@@ -185,26 +188,38 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
             }
         }
         PH_STAMP(1);
-        // block exclusive scan of the counts (cells c = tid and tid + 256): wave scans + one barrier
+        // block exclusive scan in cell order (c = r*256 + tid): per-r wave scans + one barrier
         {
-            unsigned int inc0 = my_cnt[0], inc1 = my_cnt[1];
+            unsigned int inc[T_CPT];
+#pragma unroll
+            for (int r = 0; r < T_CPT; ++r) inc[r] = my_cnt[r];
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
-                const unsigned int o0 = __shfl_up(inc0, off, 64), o1 = __shfl_up(inc1, off, 64);
-                if (lane >= off) { inc0 += o0; inc1 += o1; }
-            }
-            if (lane == 63) { sm.scan_tmp[wave] = inc0; sm.scan_tmp[4 + wave] = inc1; }
-            __syncthreads();
-            unsigned int base0 = 0, base1 = 0, tot0 = 0, tot1 = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const unsigned int t0 = sm.scan_tmp[w], t1 = sm.scan_tmp[4 + w];
-                if (w < wave) { base0 += t0; base1 += t1; }
-                tot0 += t0; tot1 += t1;
+                for (int r = 0; r < T_CPT; ++r) {
+                    const unsigned int o = __shfl_up(inc[r], off, 64);
+                    if (lane >= off) inc[r] += o;
+                }
             }
-            if (tid < ncell) sm.c_off[tid] = base0 + inc0 - my_cnt[0];
-            if (tid + 256 < ncell) sm.c_off[tid + 256] = tot0 + base1 + inc1 - my_cnt[1];
-            if (tid == 0) { sm.c_off[ncell] = tot0 + tot1; sm.total = tot0 + tot1; }
+            if (lane == 63) {
+#pragma unroll
+                for (int r = 0; r < T_CPT; ++r) sm.scan_tmp[r * 4 + wave] = inc[r];
+            }
+            __syncthreads();
+            unsigned int run = 0;  // sum of all cells before (r, wave 0)
+#pragma unroll
+            for (int r = 0; r < T_CPT; ++r) {
+                unsigned int base = run;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned int t = sm.scan_tmp[r * 4 + w];
+                    if (w < wave) base += t;
+                    run += t;
+                }
+                const int c = tid + r * 256;
+                if (c < ncell) sm.c_off[c] = base + inc[r] - my_cnt[r];
+            }
+            if (tid == 0) { sm.c_off[ncell] = run; sm.total = run; }
             __syncthreads();
         }
         PH_STAMP(2);
@@ -282,7 +297,7 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         if (clamped) {
             push_item(list_b, &sm.counts[L_HARD], ax, ay, az, DBL_MAX, POS_NONE, (unsigned int)qi);
         } else if (!staged) {
-            push_item(list1, &sm.counts[L_RING1], ax, ay, az, DBL_MAX, POS_NONE, (unsigned int)qi);
+            push_item(list_b, &sm.counts[L_HARD], ax, ay, az, DBL_MAX, POS_NONE, (unsigned int)qi);
         } else {
             // distance from the query to the boundary of the staged box
             const double cell = gv.cell0 * (double)(1ll << (2 * level));
@@ -302,7 +317,7 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
                 res_pos[qi] = bpos;
                 if (res_d2) res_d2[qi] = bd2;
             } else if (bound2 <= 4.0 * safe0 * safe0) {
-                push_item(list_a, &sm.counts[L_RING2], ax, ay, az, bd2, bpos, (unsigned int)qi);
+                push_item(list_b, &sm.counts[L_HARD], ax, ay, az, bd2, bpos, (unsigned int)qi);
             } else {
                 push_item(list_b, &sm.counts[L_HARD], ax, ay, az, bd2, bpos, (unsigned int)qi);
             }
@@ -549,6 +564,14 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
         const int cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
         const int cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
         const int cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
+        if (!clamped && it.best_pos == POS_NONE) {
+            // nothing known yet (tile too large to stage): the query's own level-0 cell gives a first bound
+            unsigned int s, e;
+            if (lookup_cell(gv.table[0], gv.mask[0], (unsigned int)cx, (unsigned int)cy, (unsigned int)cz, &s, &e)) {
+                scan_range(gv.pts, s + lane, e, 64, ax, ay, az, bd2, bid, bpos);
+                bound2 = fmin(bound2, wave_min(bd2));
+            }
+        }
         // start level: the smallest one whose 3x3x3 block covers the bound ball
         int s_level = -1;
         if (!clamped && bound2 < DBL_MAX) {
@@ -763,14 +786,9 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc,
     hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
                        write_back, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, l1, la, lb, sc->counts, ctx->d_debug);
     pcr_prof_mark(ctx, 1);
-    hipLaunchKernelGGL(grid_ring1_list_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, idx->view, (const work_item*)l1, max_d2,
-                       gated ? 1 : 0, sc->res_pos, sc->res_d2, la, lb, sc->counts);
     hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)sc->counts, nblocks, sc->offs);
     // fixed grids walk the compacted lists (their lengths are only known on the device)
-    const int g2 = nblocks < 2 * ctx->cu_count ? nblocks : 2 * ctx->cu_count;
     const int g3 = nblocks < 8 * ctx->cu_count ? nblocks : 8 * ctx->cu_count;
-    hipLaunchKernelGGL(grid_ring2_kernel, dim3(g2), dim3(256), 0, ctx->stream, idx->view, (const work_item*)la,
-                       (const unsigned int*)sc->offs, nblocks, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2);
     hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, ctx->stream, idx->view, (const work_item*)lb,
                        (const unsigned int*)(sc->offs + nblocks + 1), nblocks, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2);
     PCR_HIP(ctx, hipGetLastError());

@@ -28,3 +28,9 @@ print("slowest blocks:", [(int(cyc[i]), int(P[i]), int(lvl[i]), int(ncell[i])) f
 print("corr cycles~P", np.corrcoef(cyc, P)[0, 1])
 print("phase stamps (cycles since start) median: load+box %.0f | lookups %.0f | scan %.0f | staged(last round) %.0f | eval done %.0f | end %.0f" % (*np.median(ph, axis=0), np.median(cyc)))
 print("phase stamps p90:", np.percentile(ph, 90, axis=0))
+one = P <= 512
+d = np.diff(np.c_[np.zeros(nb), ph, cyc], axis=1)
+names = ["load+box", "lookups", "scan", "staging", "eval", "merge+lists"]
+print("single-round tiles (P<=512): n=%d, median P=%.0f" % (one.sum(), np.median(P[one])))
+for k, nm in enumerate(names):
+    print("   %-12s median %7.0f  p90 %7.0f cycles" % (nm, np.median(d[one, k]), np.percentile(d[one, k], 90)))
