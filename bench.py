@@ -167,7 +167,7 @@ def main():
         ctx.profile(False)
         kern = {}
         if a.nn == "grid":
-            names = ["grid_tile_kernel", "grid_ring1_list+ring2+hard_kernels", "grid_accumulate_kernel", "reduce_partials_kernel"]
+            names = ["grid_tile_kernel", "grid_hard_kernel", "grid_accumulate_kernel", "-"]
         else:
             names = ["brute_nn_kernel", "brute_merge_kernel", "-", "brute_reduce_partials_kernel"]
         for nm, ms in zip(names, prof_ms):

@@ -13,12 +13,12 @@
 //           KITTI-shaped pair: 8 lanes/query over the 27 cells with lane-owned cells (117 us),
 //           flattened directory (174 us), prune-then-visit (88-180 us) -- dependent
 //           lookup->scan chains and uncoalesced 32-B reads dominate there.
-//   ring 1  (per query, 8 lanes) only for tiles whose box is too large to stage.
-//   ring 2  queries whose bound ball fits in their own 5x5x5 block: the 98 shell cells.
-//   hard    everything else, one wave per query: pruned top-down descent of the nested cell
-//           hierarchy (cells are contiguous runs of the Morton-sorted target at every level).
-// Work lists between stages are per-block segments (no global append counter: a single
-// returning atomic word saturates at ~88 appends/us on this chip).
+//   hard    every query the tile stage could not resolve (bound ball sticks out of the staged box,
+//           or the tile's box holds too many points to stage), one wave per query: pruned top-down
+//           descent of the nested cell hierarchy (cells are contiguous runs of the Morton-sorted
+//           target at every level), 64 children box-tested per step.
+// The unresolved queries of a tile are appended to ONE global list with a single atomic per block
+// (a per-query global append saturates at ~88 appends/us on this chip and cost more than the search).
 // Pruning only ever skips a cell whose box distance exceeds a bound that is itself >= the
 // final answer, so every stage returns the exact nearest neighbour (lowest index on ties).
 #include <cmath>
@@ -30,7 +30,6 @@ constexpr int T_MAXC = 1024;                // cells in a tile box
 constexpr int T_CPT = T_MAXC / 256;         // cells looked up per thread
 constexpr int T_PMAX = 512;                 // points staged per round
 constexpr unsigned int T_PCAP = 4 * T_PMAX;   // tiles with more candidate points than this go per-query
-constexpr int SG = 8;                       // lanes per query in rings 1 and 2
 constexpr unsigned int HARD_SCAN_T = 192;   // the hard stage scans cells up to this size, descends into bigger ones
 constexpr int HARD_STACK = 160;
 constexpr long long ID_NONE = 0x7fffffffffffffffll;
@@ -66,20 +65,6 @@ __device__ static inline double sq_pos(double v) {
     return v * v;
 }
 
-// per-block work lists: list[block * TQ + k], k < counts[block * 3 + which]
-enum { L_RING1 = 0, L_RING2 = 1, L_HARD = 2 };
-
-__device__ static inline void push_item(work_item* __restrict__ list, unsigned int* s_count, double ax, double ay, double az,
-                                        double bd2, unsigned int bpos, unsigned int qi) {
-    const unsigned int w = blockIdx.x * TQ + atomicAdd(s_count, 1u);  // LDS atomic
-    work_item it;
-    it.ax = ax; it.ay = ay; it.az = az;
-    it.best_d2 = bd2;
-    it.best_pos = bpos;
-    it.qi = qi;
-    list[w] = it;
-}
-
 // -------------------------------------------------------------------- tile
 struct tile_smem {
     double px[T_PMAX + 4], py[T_PMAX + 4], pz[T_PMAX + 4];  // staged candidates (SoA: broadcast reads), padded to a multiple of 4
@@ -94,14 +79,12 @@ struct tile_smem {
     int box_lo[3], dims[3];
     int level, ncell;
     unsigned int total;
-    unsigned int counts[3];
 };
 
 __global__ void __launch_bounds__(256)
 grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
-                 int gated, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ list1,
-                 work_item* __restrict__ list_a, work_item* __restrict__ list_b, unsigned int* __restrict__ counts /* [block][3] */,
-                 unsigned long long* __restrict__ dbg) {
+                 int gated, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
+                 unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg) {
     __shared__ tile_smem sm;
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_ph[5] = {0, 0, 0, 0, 0};
@@ -109,7 +92,6 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long qi = (long long)blockIdx.x * TQ + lane;  // every wave holds the same 64 queries
     const bool qvalid = qi < nq;
-    if (tid < 3) sm.counts[tid] = 0;
     // ---- load + transform the tile's queries (wave 0 writes back)
     double ax = 0, ay = 0, az = 0;
     bool clamped = false;
@@ -287,230 +269,65 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
     sm.m_id[wave][lane] = (bid == ID_NONE) ? 0x7fffffff : (int)bid;
     sm.m_pos[wave][lane] = bpos;
     __syncthreads();
-    if (wave == 0 && qvalid) {
+    unsigned int n_unres = 0;
+    if (wave == 0) {
+        bool unres = false;
+        if (qvalid) {
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const double od2 = sm.m_d2[w][lane];
-            const long long oid = sm.m_id[w][lane];
-            if (sm.m_pos[w][lane] != POS_NONE && better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; bpos = sm.m_pos[w][lane]; }
-        }
-        if (clamped) {
-            push_item(list_b, &sm.counts[L_HARD], ax, ay, az, DBL_MAX, POS_NONE, (unsigned int)qi);
-        } else if (!staged) {
-            push_item(list_b, &sm.counts[L_HARD], ax, ay, az, DBL_MAX, POS_NONE, (unsigned int)qi);
-        } else {
-            // distance from the query to the boundary of the staged box
-            const double cell = gv.cell0 * (double)(1ll << (2 * level));
-            const int bl = (int)(PCR_COORD_BIAS >> (2 * level));
-            double db = DBL_MAX;
-            const double a[3] = {ax, ay, az};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double blo = gv.lo[k] + (double)(sm.box_lo[k] - bl) * cell;
-                const double bhi = gv.lo[k] + (double)(sm.box_lo[k] + sm.dims[k] - bl) * cell;
-                db = fmin(db, fmin(a[k] - blo, bhi - a[k]));
+            for (int w = 1; w < 4; ++w) {
+                const double od2 = sm.m_d2[w][lane];
+                const long long oid = sm.m_id[w][lane];
+                if (sm.m_pos[w][lane] != POS_NONE && better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; bpos = sm.m_pos[w][lane]; }
             }
-            db = fmax(db - cell * 1e-9, 0.0);
-            const double bound2 = gated ? fmin(bd2, max_d2) : bd2;
-            const double safe0 = gv.cell0 * (1.0 - 1e-9);
-            if (bound2 <= db * db) {  // the bound ball lies inside the staged box: exact
-                res_pos[qi] = bpos;
-                if (res_d2) res_d2[qi] = bd2;
-            } else if (bound2 <= 4.0 * safe0 * safe0) {
-                push_item(list_b, &sm.counts[L_HARD], ax, ay, az, bd2, bpos, (unsigned int)qi);
+            if (clamped || !staged) {
+                unres = true;  // nothing usable is known about this query yet
+                bd2 = DBL_MAX;
+                bpos = POS_NONE;
             } else {
-                push_item(list_b, &sm.counts[L_HARD], ax, ay, az, bd2, bpos, (unsigned int)qi);
+                // distance from the query to the boundary of the staged box
+                const double cell = gv.cell0 * (double)(1ll << (2 * level));
+                const int bl = (int)(PCR_COORD_BIAS >> (2 * level));
+                double db = DBL_MAX;
+                const double a[3] = {ax, ay, az};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double blo = gv.lo[k] + (double)(sm.box_lo[k] - bl) * cell;
+                    const double bhi = gv.lo[k] + (double)(sm.box_lo[k] + sm.dims[k] - bl) * cell;
+                    db = fmin(db, fmin(a[k] - blo, bhi - a[k]));
+                }
+                db = fmax(db - cell * 1e-9, 0.0);
+                const double bound2 = gated ? fmin(bd2, max_d2) : bd2;
+                if (bound2 <= db * db) {  // the bound ball lies inside the staged box: exact
+                    res_pos[qi] = bpos;
+                    if (res_d2) res_d2[qi] = bd2;
+                } else {
+                    unres = true;
+                }
+            }
+        }
+        // one append per block: reserve a run of the global hard list for this tile's unresolved queries
+        const unsigned long long m = __ballot(unres);
+        n_unres = __popcll(m);
+        if (m) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(hard_count, n_unres);
+            base = __shfl(base, 0, 64);
+            if (unres) {
+                work_item it;
+                it.ax = ax; it.ay = ay; it.az = az;
+                it.best_d2 = bd2;
+                it.best_pos = bpos;
+                it.qi = (unsigned int)qi;
+                hard_list[base + __popcll(m & ((1ull << lane) - 1ull))] = it;
             }
         }
     }
-    __syncthreads();
-    if (tid < 3) counts[blockIdx.x * 3 + tid] = sm.counts[tid];
     if (dbg && tid == 0) {
         dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - t_start;
         for (int i = 0; i < 5; ++i) dbg[(1 << 16) + blockIdx.x * 8 + i] = t_ph[i];
         dbg[blockIdx.x * 4 + 1] = (level >= 0) ? sm.total : 0xffffffffu;
         dbg[blockIdx.x * 4 + 2] = ((unsigned long long)(level + 1) << 32) | (unsigned)sm.ncell;
-        dbg[blockIdx.x * 4 + 3] = ((unsigned long long)sm.counts[0] << 40) | ((unsigned long long)sm.counts[1] << 20) | sm.counts[2];
-    }
-}
-
-// ------------------------------------------------------------- ring 1 / 2
-// Per-axis squared distance from the query to the slab of cells at offset d (|d| <= 2),
-// shrunk by a rounding slack so that pruning stays conservative.
-struct axis_d2 {
-    double m2, m1, p1, p2;  // d = -2, -1, +1, +2   (d = 0 -> 0)
-    __device__ inline double at(int d) const { return d == 0 ? 0.0 : d == -1 ? m1 : d == 1 ? p1 : d == -2 ? m2 : p2; }
-};
-
-__device__ static inline axis_d2 make_axis(double f, double cell) {
-    const double slack = cell * 1e-9;
-    axis_d2 a;
-    a.m1 = sq_pos(f - slack);
-    a.p1 = sq_pos(cell - f - slack);
-    a.m2 = sq_pos(f + cell - slack);
-    a.p2 = sq_pos(2.0 * cell - f - slack);
-    return a;
-}
-
-// Ring 1 for the queries of tiles that could not be staged: own cell by the whole group, then
-// lane-owned neighbour cells pruned against the bound.  Appends to the block's ring-2 / hard lists.
-__global__ void __launch_bounds__(256)
-grid_ring1_list_kernel(pcr_grid_view gv, const work_item* __restrict__ list1, double max_d2, int gated, unsigned int* __restrict__ res_pos,
-                       double* __restrict__ res_d2, work_item* __restrict__ list_a, work_item* __restrict__ list_b,
-                       unsigned int* __restrict__ counts) {
-    constexpr int G = SG;
-    __shared__ unsigned int s_counts[3];
-    if (threadIdx.x < 3) s_counts[threadIdx.x] = counts[blockIdx.x * 3 + threadIdx.x];
-    __syncthreads();
-    const unsigned int count = s_counts[L_RING1];
-    __syncthreads();
-    const int gl = threadIdx.x % G;
-    const pcr_cell_slot* __restrict__ tab = gv.table[0];
-    const unsigned int mask = gv.mask[0];
-    const double cell = gv.cell0;
-    for (unsigned int g = threadIdx.x / G; g < count; g += 256 / G) {
-        const work_item it = list1[(size_t)blockIdx.x * TQ + g];
-        const double ax = it.ax, ay = it.ay, az = it.az;
-        bool clamped = false;
-        const int cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
-        const int cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
-        const int cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
-        double bd2 = DBL_MAX;
-        long long bid = ID_NONE;
-        unsigned int bpos = POS_NONE;
-        {
-            unsigned int s, e;
-            if (lookup_cell(tab, mask, (unsigned int)cx, (unsigned int)cy, (unsigned int)cz, &s, &e))
-                scan_range(gv.pts, s + gl, e, G, ax, ay, az, bd2, bid, bpos);
-            group_best<G>(bd2, bid, bpos);
-        }
-        double bound2 = gated ? fmin(bd2, max_d2) : bd2;
-        const axis_d2 dx2 = make_axis((ax - gv.lo[0]) - (double)(cx - (int)PCR_COORD_BIAS) * cell, cell);
-        const axis_d2 dy2 = make_axis((ay - gv.lo[1]) - (double)(cy - (int)PCR_COORD_BIAS) * cell, cell);
-        const axis_d2 dz2 = make_axis((az - gv.lo[2]) - (double)(cz - (int)PCR_COORD_BIAS) * cell, cell);
-#pragma unroll
-        for (int i = 0; i < (27 + G - 1) / G; ++i) {
-            const int n = gl + i * G;
-            if (n < 27 && n != 13) {
-                const int dx = n % 3 - 1, dy = (n / 3) % 3 - 1, dz = n / 9 - 1;
-                const unsigned int nx = (unsigned int)(cx + dx), ny = (unsigned int)(cy + dy), nz = (unsigned int)(cz + dz);
-                if ((dx2.at(dx) + dy2.at(dy)) + dz2.at(dz) <= bound2 && nx <= (unsigned int)PCR_COORD_MAX &&
-                    ny <= (unsigned int)PCR_COORD_MAX && nz <= (unsigned int)PCR_COORD_MAX) {
-                    unsigned int s, e;
-                    if (lookup_cell(tab, mask, nx, ny, nz, &s, &e)) scan_range(gv.pts, s, e, 1, ax, ay, az, bd2, bid, bpos);
-                }
-            }
-        }
-        group_best<G>(bd2, bid, bpos);
-        if (gl == 0) {
-            bound2 = gated ? fmin(bd2, max_d2) : bd2;
-            const double safe = cell * (1.0 - 1e-9);
-            if (bound2 <= safe * safe) {
-                res_pos[it.qi] = bpos;
-                if (res_d2) res_d2[it.qi] = bd2;
-            } else if (bound2 <= 4.0 * safe * safe) {
-                push_item(list_a, &s_counts[L_RING2], ax, ay, az, bd2, bpos, it.qi);
-            } else {
-                push_item(list_b, &s_counts[L_HARD], ax, ay, az, bd2, bpos, it.qi);
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) counts[blockIdx.x * 3 + threadIdx.x] = s_counts[threadIdx.x];
-}
-
-// Exclusive prefix of the per-block ring-2 and hard counts, so that the (few, unevenly spread)
-// items can be dealt evenly to the waves of the next two kernels: offs[which][b], which = 0 ring 2, 1 hard.
-__global__ void __launch_bounds__(1024)
-grid_prefix_kernel(const unsigned int* __restrict__ counts, int nblocks, unsigned int* __restrict__ offs) {
-    __shared__ unsigned int s_w[2][16];
-    __shared__ unsigned int s_carry[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 2) s_carry[tid] = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
-        const int b = b0 + tid;
-        const unsigned int c0 = b < nblocks ? counts[b * 3 + L_RING2] : 0, c1 = b < nblocks ? counts[b * 3 + L_HARD] : 0;
-        unsigned int i0 = c0, i1 = c1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64);
-            if (lane >= off) { i0 += o0; i1 += o1; }
-        }
-        if (lane == 63) { s_w[0][wave] = i0; s_w[1][wave] = i1; }
-        __syncthreads();
-        unsigned int base0 = s_carry[0], base1 = s_carry[1], tot0 = 0, tot1 = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) { base0 += s_w[0][w]; base1 += s_w[1][w]; }
-            tot0 += s_w[0][w]; tot1 += s_w[1][w];
-        }
-        if (b < nblocks) { offs[b] = base0 + i0 - c0; offs[(nblocks + 1) + b] = base1 + i1 - c1; }
-        __syncthreads();
-        if (tid == 0) { s_carry[0] += tot0; s_carry[1] += tot1; }
-        __syncthreads();
-    }
-    if (tid == 0) { offs[nblocks] = s_carry[0]; offs[(nblocks + 1) + nblocks] = s_carry[1]; }
-}
-
-// compact index i -> (block, slot): largest b with offs[b] <= i
-__device__ static inline work_item locate_item(const work_item* __restrict__ list, const unsigned int* __restrict__ offs, int nblocks,
-                                               unsigned int i) {
-    int lo = 0, hi = nblocks - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (offs[mid] <= i) lo = mid;
-        else hi = mid - 1;
-    }
-    return list[(size_t)lo * TQ + (i - offs[lo])];
-}
-
-// Ring 2: the 98 shell cells of the query's 5x5x5 block, lane-owned, pruned against the bound.
-__global__ void __launch_bounds__(256)
-grid_ring2_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ offs, int nblocks, double max_d2,
-                  int gated, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2) {
-    constexpr int G = SG;
-    const int gl = threadIdx.x % G;
-    const unsigned int count = offs[nblocks];
-    const pcr_cell_slot* __restrict__ tab = gv.table[0];
-    const unsigned int mask = gv.mask[0];
-    const double cell = gv.cell0;
-    for (unsigned int g = blockIdx.x * (256 / G) + threadIdx.x / G; g < count; g += gridDim.x * (256 / G)) {
-        const work_item it = locate_item(list, offs, nblocks, g);
-        const double ax = it.ax, ay = it.ay, az = it.az;
-        double bd2 = DBL_MAX;
-        long long bid = ID_NONE;
-        unsigned int bpos = POS_NONE;
-        if (gl == 0 && it.best_pos != POS_NONE) {
-            bd2 = it.best_d2;
-            bpos = it.best_pos;
-            bid = gv.pts[bpos].id;
-        }
-        const double bound2 = gated ? fmin(it.best_d2, max_d2) : it.best_d2;
-        bool clamped = false;
-        const int cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
-        const int cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
-        const int cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
-        const axis_d2 dx2 = make_axis((ax - gv.lo[0]) - (double)(cx - (int)PCR_COORD_BIAS) * cell, cell);
-        const axis_d2 dy2 = make_axis((ay - gv.lo[1]) - (double)(cy - (int)PCR_COORD_BIAS) * cell, cell);
-        const axis_d2 dz2 = make_axis((az - gv.lo[2]) - (double)(cz - (int)PCR_COORD_BIAS) * cell, cell);
-#pragma unroll 4
-        for (int i = 0; i < (125 + G - 1) / G; ++i) {
-            const int c = gl + i * G;
-            const int ix = c % 5, iy = (c / 5) % 5, iz = c / 25;
-            const bool shell = c < 125 && (ix == 0 || ix == 4 || iy == 0 || iy == 4 || iz == 0 || iz == 4);
-            if (shell && (dx2.at(ix - 2) + dy2.at(iy - 2)) + dz2.at(iz - 2) <= bound2) {
-                const unsigned int nx = (unsigned int)(cx + ix - 2), ny = (unsigned int)(cy + iy - 2), nz = (unsigned int)(cz + iz - 2);
-                if (nx <= (unsigned int)PCR_COORD_MAX && ny <= (unsigned int)PCR_COORD_MAX && nz <= (unsigned int)PCR_COORD_MAX) {
-                    unsigned int s, e;
-                    if (lookup_cell(tab, mask, nx, ny, nz, &s, &e)) scan_range(gv.pts, s, e, 1, ax, ay, az, bd2, bid, bpos);
-                }
-            }
-        }
-        group_best<G>(bd2, bid, bpos);
-        if (gl == 0) {
-            res_pos[it.qi] = bpos;
-            if (res_d2) res_d2[it.qi] = bd2;
-        }
+        dbg[blockIdx.x * 4 + 3] = n_unres;
     }
 }
 
@@ -541,15 +358,15 @@ __device__ static inline double wave_min(double v) {
 }
 
 __global__ void __launch_bounds__(256)
-grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ offs, int nblocks, double max_d2,
-                 int gated, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2) {
+grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ count_p, double max_d2, int gated,
+                 unsigned int* __restrict__ res_pos, double* __restrict__ res_d2) {
     __shared__ hard_entry s_stack[4][HARD_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     hard_entry* stack = s_stack[wave];
-    const unsigned int count = offs[nblocks];
+    const unsigned int count = *count_p;
     const int top = gv.levels - 1;
     for (unsigned int w = blockIdx.x * 4 + wave; w < count; w += gridDim.x * 4) {
-        const work_item it = locate_item(list, offs, nblocks, w);
+        const work_item it = list[w];
         const double ax = it.ax, ay = it.ay, az = it.az;
         double bd2 = DBL_MAX;
         long long bid = ID_NONE;
@@ -671,8 +488,9 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
 // nn1: sorted position -> original target index, gate, scatter to the query's original slot
 __global__ void grid_finalize_nn1_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long nq, const unsigned int* __restrict__ res_pos,
                                          const double* __restrict__ res_d2, double max_d2, int gated, int* __restrict__ idx_out,
-                                         double* __restrict__ d2_out) {
+                                         double* __restrict__ d2_out, unsigned int* __restrict__ hard_count) {
     const long long qi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi == 0) *hard_count = 0;  // next search starts with an empty list (stream-ordered)
     if (qi >= nq) return;
     const unsigned int pos = res_pos[qi];
     const double d2 = res_d2[qi];
@@ -687,7 +505,8 @@ __global__ void grid_finalize_nn1_kernel(pcr_grid_view gv, const pcr_pt* __restr
 // block, summed in fixed order by reduce_partials_kernel (bitwise reproducible run to run).
 __global__ void __launch_bounds__(256)
 grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long nq, pcr_xform x, int apply_x,
-                       const unsigned int* __restrict__ res_pos, double max_d2, int gated, double* __restrict__ partials) {
+                       const unsigned int* __restrict__ res_pos, double max_d2, int gated, double* __restrict__ partials,
+                       unsigned int* __restrict__ ticket, double* __restrict__ out, unsigned int* __restrict__ hard_count) {
     __shared__ double s_part[4][PCR_NMOM];
     double m[PCR_NMOM];
 #pragma unroll
@@ -730,35 +549,44 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
         const double v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
         partials[(long long)blockIdx.x * PCR_NMOM + threadIdx.x] = v;
     }
-}
-
-// out[k] = sum_b partials[b][k], fixed association order: 32 strided slices then a tree.
-__global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
-                                                               double* __restrict__ out) {
-    __shared__ double s[32][32];
-    const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    double v = 0.0;
-    if (k < PCR_NMOM) {
-        for (int b = slice; b < nblocks; b += 32) v += partials[(long long)b * PCR_NMOM + k];
-    }
-    s[slice][k] = v;
+    // ---- the block that arrives last sums the slabs in fixed order (saves a launch boundary).
+    // Hand-off per the CDNA4 recipe: drained stores -> barrier -> agent-scope release -> ticket;
+    // last arriver: agent-scope acquire -> barrier -> plain loads.
+    __shared__ unsigned int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int st = 16; st > 0; st >>= 1) {
-        if (slice < st) s[slice][k] += s[slice + st][k];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *ticket = 0;  // ready for the next launch (stream-ordered)
+            *hard_count = 0;
+        }
     }
-    if (slice == 0 && k < PCR_NMOM) out[k] = s[0][k];
+    __syncthreads();
+    if (!s_last) return;
+    __shared__ double s_red[8][32];
+    const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;  // 8 strided slices, then a fixed tree
+    double v = 0.0;
+    if (k < PCR_NMOM)
+        for (int b = slice; b < (int)gridDim.x; b += 8) v += partials[(long long)b * PCR_NMOM + k];
+    s_red[slice][k] = v;
+    __syncthreads();
+    if (slice == 0 && k < PCR_NMOM)
+        out[k] = ((s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k])) + ((s_red[4][k] + s_red[5][k]) + (s_red[6][k] + s_red[7][k]));
 }
 
 // ------------------------------------------------------------------- host
 struct grid_scratch {
     unsigned int* res_pos = nullptr;
     double* res_d2 = nullptr;
-    work_item* lists = nullptr;      // [3][nblocks][TQ]
-    unsigned int* counts = nullptr;  // [nblocks][3]
-    unsigned int* offs = nullptr;    // [2][nblocks + 1]
+    work_item* hard_list = nullptr;   // [nq] worst case
+    unsigned int* hard_count = nullptr;
     int64_t nq = 0;
-    int nblocks = 0;
 };
 
 // Runs the search stages; leaves res_pos (and res_d2 when asked) on the device.
@@ -771,26 +599,21 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc,
     pcr_pt* q = qc->d;
     sc->nq = nq;
     const int nblocks = (int)((nq + TQ - 1) / TQ);
-    sc->nblocks = nblocks;
     if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * nq, (void**)&sc->res_pos))) return rc;
     if (want_d2 && (rc = pcr_dev_alloc(ctx, sizeof(double) * nq, (void**)&sc->res_d2))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(work_item) * 3 * TQ * (size_t)nblocks, (void**)&sc->lists))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * 3 * (size_t)nblocks, (void**)&sc->counts))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * 2 * (size_t)(nblocks + 1), (void**)&sc->offs))) return rc;
-    work_item* l1 = sc->lists;
-    work_item* la = sc->lists + (size_t)TQ * nblocks;
-    work_item* lb = sc->lists + 2 * (size_t)TQ * nblocks;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(work_item) * (size_t)nq, (void**)&sc->hard_list))) return rc;
+    sc->hard_count = ctx->d_counters + 96;  // zero at context creation, reset by the epilogue kernels
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
     pcr_prof_mark(ctx, 0);
     hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
-                       write_back, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, l1, la, lb, sc->counts, ctx->d_debug);
+                       write_back, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
     pcr_prof_mark(ctx, 1);
-    hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)sc->counts, nblocks, sc->offs);
-    // fixed grids walk the compacted lists (their lengths are only known on the device)
-    const int g3 = nblocks < 8 * ctx->cu_count ? nblocks : 8 * ctx->cu_count;
-    hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, ctx->stream, idx->view, (const work_item*)lb,
-                       (const unsigned int*)(sc->offs + nblocks + 1), nblocks, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2);
+    // a fixed grid of waves walks the hard list (its length is only known on the device)
+    const long long want = (nq + 3) / 4;
+    const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
+    hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, ctx->stream, idx->view, (const work_item*)sc->hard_list,
+                       (const unsigned int*)sc->hard_count, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
@@ -798,9 +621,7 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc,
 static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
     pcr_dev_free(ctx, sc->res_pos, sizeof(unsigned int) * sc->nq);
     if (sc->res_d2) pcr_dev_free(ctx, sc->res_d2, sizeof(double) * sc->nq);
-    pcr_dev_free(ctx, sc->lists, sizeof(work_item) * 3 * TQ * (size_t)sc->nblocks);
-    pcr_dev_free(ctx, sc->counts, sizeof(unsigned int) * 3 * (size_t)sc->nblocks);
-    pcr_dev_free(ctx, sc->offs, sizeof(unsigned int) * 2 * (size_t)(sc->nblocks + 1));
+    pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)sc->nq);
 }
 
 int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xform* x, double max_d2, int32_t* d_idx, double* d_d2) {
@@ -811,7 +632,7 @@ int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xf
     const int64_t nq = qc->n;
     const int grid = (int)((nq + 255) / 256);
     hipLaunchKernelGGL(grid_finalize_nn1_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq,
-                       (const unsigned int*)sc.res_pos, (const double*)sc.res_d2, max_d2, gated ? 1 : 0, d_idx, d_d2);
+                       (const unsigned int*)sc.res_pos, (const double*)sc.res_d2, max_d2, gated ? 1 : 0, d_idx, d_d2, sc.hard_count);
     PCR_HIP(ctx, hipGetLastError());
     grid_scratch_free(ctx, &sc);
     return PCR_OK;
@@ -824,15 +645,15 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     int rc = grid_search_launch(ctx, idx, qc, x, write_back, max_d2, gated, false, &sc);
     if (rc) return rc;
     const int64_t nq = qc->n;
-    int grid = (int)((nq + 255) / 256);
-    if (grid > 4 * ctx->cu_count) grid = 4 * ctx->cu_count;
+    int grid = (int)((nq + 511) / 512);  // two queries per thread
+    if (grid > 2 * ctx->cu_count) grid = 2 * ctx->cu_count;
     if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid))) return rc;
     // after a write-back pass the cloud already holds the transformed points
     pcr_prof_mark(ctx, 2);
     hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, *x,
-                       write_back ? 0 : 1, (const unsigned int*)sc.res_pos, max_d2, gated ? 1 : 0, ctx->d_partials);
+                       write_back ? 0 : 1, (const unsigned int*)sc.res_pos, max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
+                       d_moments, sc.hard_count);
     pcr_prof_mark(ctx, 3);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ctx->d_partials, grid, d_moments);
     pcr_prof_mark(ctx, 4);
     PCR_HIP(ctx, hipGetLastError());
     pcr_prof_finish(ctx);

@@ -17,7 +17,7 @@ L.check(L.lib().pcr_debug_read(ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint
 ph = buf[(1 << 16):].reshape(nb, 8)[:, :5].astype(np.float64)
 b = buf[: nb * 4].reshape(nb, 4)
 cyc = b[:, 0].astype(np.float64); P = b[:, 1].astype(np.float64); lvl = (b[:, 2] >> np.uint64(32)).astype(int) - 1; ncell = (b[:, 2] & np.uint64(0xffffffff)).astype(int)
-c0 = (b[:, 3] >> np.uint64(40)).astype(int); c1 = ((b[:, 3] >> np.uint64(20)) & np.uint64(0xfffff)).astype(int); c2 = (b[:, 3] & np.uint64(0xfffff)).astype(int)
+c0 = b[:, 3].astype(int); c1 = c0 * 0; c2 = c0 * 0
 print("cell", index.cell, "blocks", nb)
 print("cycles(100MHz ticks?) pct 50/90/99/max", np.percentile(cyc, [50, 90, 99, 100]), "sum", cyc.sum())
 print("P pct 50/90/99/max", np.percentile(P, [50, 90, 99, 100]), "mean", P.mean())
