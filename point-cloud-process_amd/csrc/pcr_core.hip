@@ -35,6 +35,8 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
     pcr_ctx* c = new pcr_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete c; return PCR_E_HIP; }
+    // the ICP loop waits for a 160-byte read-back every iteration: spin instead of sleeping on an interrupt
+    hipSetDeviceFlags(hipDeviceScheduleSpin);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         c->cu_count = prop.multiProcessorCount;

@@ -511,26 +511,44 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
     double m[PCR_NMOM];
 #pragma unroll
     for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
-    for (long long qi = (long long)blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += (long long)gridDim.x * blockDim.x) {
-        const unsigned int pos = res_pos[qi];
-        if (pos == POS_NONE) continue;
-        const pcr_pt p = q[qi];
-        double ax = p.x, ay = p.y, az = p.z;
-        if (apply_x) xform_apply(x, p, &ax, &ay, &az);
-        const pcr_pt b = gv.pts[pos];
-        const double d2 = dist2(ax, ay, az, b);
-        if (gated && !(d2 < max_d2)) continue;
-        const double a0 = ax - gv.origin[0], a1 = ay - gv.origin[1], a2 = az - gv.origin[2];
-        const double b0 = b.x - gv.origin[0], b1 = b.y - gv.origin[1], b2 = b.z - gv.origin[2];
-        m[0] += 1.0;
-        m[1] += a0; m[2] += a1; m[3] += a2;
-        m[4] += b0; m[5] += b1; m[6] += b2;
-        m[7] += b0 * a0; m[8] += b0 * a1; m[9] += b0 * a2;
-        m[10] += b1 * a0; m[11] += b1 * a1; m[12] += b1 * a2;
-        m[13] += b2 * a0; m[14] += b2 * a1; m[15] += b2 * a2;
-        m[16] += (a0 * a0 + a1 * a1) + a2 * a2;
-        m[17] += (b0 * b0 + b1 * b1) + b2 * b2;
-        m[18] += d2;
+    // batches of 4 queries per thread: the 4 result slots, the 4 query records and then the 4 matched
+    // target records are each loaded together (three memory round trips per batch instead of twelve)
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long q0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < nq; q0 += 4 * stride) {
+        unsigned int pos[4];
+        pcr_pt p[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long qi = q0 + u * stride;
+            pos[u] = qi < nq ? res_pos[qi] : POS_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long qi = q0 + u * stride;
+            if (qi < nq) p[u] = q[qi];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pos[u] != POS_NONE) b[u] = gv.pts[pos[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (pos[u] == POS_NONE) continue;
+            double ax = p[u].x, ay = p[u].y, az = p[u].z;
+            if (apply_x) xform_apply(x, p[u], &ax, &ay, &az);
+            const double d2 = dist2(ax, ay, az, b[u]);
+            if (gated && !(d2 < max_d2)) continue;
+            const double a0 = ax - gv.origin[0], a1 = ay - gv.origin[1], a2 = az - gv.origin[2];
+            const double b0 = b[u].x - gv.origin[0], b1 = b[u].y - gv.origin[1], b2 = b[u].z - gv.origin[2];
+            m[0] += 1.0;
+            m[1] += a0; m[2] += a1; m[3] += a2;
+            m[4] += b0; m[5] += b1; m[6] += b2;
+            m[7] += b0 * a0; m[8] += b0 * a1; m[9] += b0 * a2;
+            m[10] += b1 * a0; m[11] += b1 * a1; m[12] += b1 * a2;
+            m[13] += b2 * a0; m[14] += b2 * a1; m[15] += b2 * a2;
+            m[16] += (a0 * a0 + a1 * a1) + a2 * a2;
+            m[17] += (b0 * b0 + b1 * b1) + b2 * b2;
+            m[18] += d2;
+        }
     }
 #pragma unroll
     for (int k = 0; k < PCR_NMOM - 1; ++k) {
@@ -572,8 +590,19 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
     __shared__ double s_red[8][32];
     const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;  // 8 strided slices, then a fixed tree
     double v = 0.0;
-    if (k < PCR_NMOM)
-        for (int b = slice; b < (int)gridDim.x; b += 8) v += partials[(long long)b * PCR_NMOM + k];
+    if (k < PCR_NMOM) {
+        // <= 256 slabs: up to 32 per slice, loaded 8 at a time (independent loads), added in slab order
+        for (int b0 = slice; b0 < (int)gridDim.x; b0 += 64) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 8 * u;
+                t[u] = b < (int)gridDim.x ? partials[(long long)b * PCR_NMOM + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+    }
     s_red[slice][k] = v;
     __syncthreads();
     if (slice == 0 && k < PCR_NMOM)
@@ -645,8 +674,8 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     int rc = grid_search_launch(ctx, idx, qc, x, write_back, max_d2, gated, false, &sc);
     if (rc) return rc;
     const int64_t nq = qc->n;
-    int grid = (int)((nq + 511) / 512);  // two queries per thread
-    if (grid > 2 * ctx->cu_count) grid = 2 * ctx->cu_count;
+    int grid = (int)((nq + 1023) / 1024);  // four queries per thread
+    if (grid > ctx->cu_count) grid = ctx->cu_count;
     if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid))) return rc;
     // after a write-back pass the cloud already holds the transformed points
     pcr_prof_mark(ctx, 2);

@@ -167,14 +167,14 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
         pcr_xform x;
         pcr_xform_from_T(T_cur, &x);
         // main.py:110 / icp_template.py:195: the source is transformed in place, fused into the pass
-        PCR_HIP(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+        if (ctx->profile) PCR_HIP(ctx, hipEventRecord(ctx->ev2, ctx->stream));
         rc = icp_pass(ctx, index, source, &x, params->max_d2, 1, d_mom);
         if (rc) break;
-        PCR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
+        if (ctx->profile) PCR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
         PCR_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_mom, sizeof(double) * PCR_NMOM, hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         float ms = 0;
-        hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3);
+        if (ctx->profile) hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3);  // per-pass kernel time only while profiling
         nn_ms += ms;
         ++launches;
         T_mul(T_cur, T_total, T_total);
