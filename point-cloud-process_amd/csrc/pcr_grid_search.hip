@@ -28,8 +28,8 @@
 constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
 constexpr int T_MAXC = 1024;                // cells in a tile box
 constexpr int T_CPT = T_MAXC / 256;         // cells looked up per thread
-constexpr int T_PMAX = 512;                 // points staged per round
-constexpr unsigned int T_PCAP = 4 * T_PMAX;   // tiles with more candidate points than this go per-query
+constexpr int T_PMAX = 1024;                // points staged per round
+constexpr unsigned int T_PCAP = 2 * T_PMAX;   // tiles with more candidate points than this go per-query
 constexpr unsigned int HARD_SCAN_T = 192;   // the hard stage scans cells up to this size, descends into bigger ones
 constexpr int HARD_STACK = 160;
 constexpr long long ID_NONE = 0x7fffffffffffffffll;
@@ -67,13 +67,11 @@ __device__ static inline double sq_pos(double v) {
 
 // -------------------------------------------------------------------- tile
 struct tile_smem {
-    double px[T_PMAX + 4], py[T_PMAX + 4], pz[T_PMAX + 4];  // staged candidates (SoA: broadcast reads), padded to a multiple of 4
-    int pid[T_PMAX];
+    float px[T_PMAX + 8], py[T_PMAX + 8], pz[T_PMAX + 8];  // staged candidates, binary32 about the tile centre (SoA, padded to 8)
     unsigned int ppos[T_PMAX];
     unsigned int c_start[T_MAXC];
     unsigned int c_off[T_MAXC + 1];  // exclusive prefix of the cell counts
-    double m_d2[4][TQ];
-    int m_id[4][TQ];
+    float m_m[4][TQ], m_s[4][TQ];  // per wave: smallest and second-smallest filter distance of each query
     unsigned int m_pos[4][TQ];
     unsigned int scan_tmp[256];
     int box_lo[3], dims[3];
@@ -206,8 +204,24 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         }
         PH_STAMP(2);
         const unsigned int total = sm.total;
+        // Filter + verify.  The 64 x P comparisons run in binary32 on coordinates taken about the tile
+        // centre (packed v_pk_* math, 2 candidates per instruction), tracking per query the smallest and the
+        // second-smallest filter distance.  With e = bound on the coordinate error, the exact nearest
+        // neighbour X and the filter's winner Y satisfy d~(X)^2 <= U(d~(Y)^2); so when the second-smallest
+        // filter distance exceeds U the winner IS the exact nearest neighbour (its distance is then
+        // recomputed in binary64, direct form).  Otherwise the query is ambiguous (near-tie or duplicate
+        // targets) and goes to the exact hard stage.
+        float fm = INFINITY, fs = INFINITY;  // smallest / second smallest filter distance
         if (total <= T_PCAP) {
             staged = true;
+            const double cellL = gv.cell0 * (double)(1ll << (2 * level));
+            const int blL = (int)(PCR_COORD_BIAS >> (2 * level));
+            const double ox = gv.lo[0] + ((double)(sm.box_lo[0] - blL) + 0.5 * sm.dims[0]) * cellL;
+            const double oy = gv.lo[1] + ((double)(sm.box_lo[1] - blL) + 0.5 * sm.dims[1]) * cellL;
+            const double oz = gv.lo[2] + ((double)(sm.box_lo[2] - blL) + 0.5 * sm.dims[2]) * cellL;
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const float qxf = (float)(ax - ox), qyf = (float)(ay - oy), qzf = (float)(az - oz);
+            const f2 qx2 = {qxf, qxf}, qy2 = {qyf, qyf}, qz2 = {qzf, qzf};
             // ---- rounds: stage up to T_PMAX points into LDS, compare every query with every staged point
             for (unsigned int base = 0; base < total; base += T_PMAX) {
                 const unsigned int wend = min(total, base + T_PMAX);
@@ -224,60 +238,72 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
                     const unsigned int j = sm.c_start[lo] + (f - sm.c_off[lo]);
                     const pcr_pt b = gv.pts[j];
                     const unsigned int k = f - base;
-                    sm.px[k] = b.x; sm.py[k] = b.y; sm.pz[k] = b.z;
-                    sm.pid[k] = (int)b.id;
+                    sm.px[k] = (float)(b.x - ox); sm.py[k] = (float)(b.y - oy); sm.pz[k] = (float)(b.z - oz);
                     sm.ppos[k] = j;
                 }
                 PH_STAMP(3);
-                if (tid < 4) { sm.px[cnt + tid] = 1e300; sm.py[cnt + tid] = 0.0; sm.pz[cnt + tid] = 0.0; }  // padding of the last group of 4
+                if (tid < 8) { sm.px[cnt + tid] = 1e30f; sm.py[cnt + tid] = 0.0f; sm.pz[cnt + tid] = 0.0f; }  // padding of the last group of 8
                 __syncthreads();
-                // evaluation: wave w takes groups of 4 staged points; lane = query.  Branch-free: strict <
-                // keeps the first of equal distances; exact ties (duplicate targets) are flagged and resolved
-                // to the lowest original index in the rare fix-up below.
-                double rd2 = DBL_MAX;  // best of this round
+                // evaluation: wave w takes groups of 8 staged points; lane = query
                 int rk = -1;
-                bool tie = false;
-                for (unsigned int k0 = wave * 4; k0 < cnt; k0 += 16) {
+                for (unsigned int k0 = wave * 8; k0 < cnt; k0 += 32) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const double dx = ax - sm.px[k0 + u], dy = ay - sm.py[k0 + u], dz = az - sm.pz[k0 + u];
-                        const double d = (dx * dx + dy * dy) + dz * dz;
-                        const bool lt = d < rd2;
-                        tie = lt ? false : (tie | (d == rd2));
-                        rd2 = lt ? d : rd2;
-                        rk = lt ? (int)(k0 + u) : rk;
+                        const unsigned int k = k0 + 2 * u;
+                        const f2 bx = *reinterpret_cast<const f2*>(&sm.px[k]);
+                        const f2 by = *reinterpret_cast<const f2*>(&sm.py[k]);
+                        const f2 bz = *reinterpret_cast<const f2*>(&sm.pz[k]);
+                        const f2 dx = qx2 - bx, dy = qy2 - by, dz = qz2 - bz;
+                        f2 d = dx * dx;
+                        d = __builtin_elementwise_fma(dy, dy, d);
+                        d = __builtin_elementwise_fma(dz, dz, d);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float dv = h ? d.y : d.x;
+                            const bool lt = dv < fm;
+                            fs = __builtin_amdgcn_fmed3f(dv, fm, fs);               // second smallest of {fm <= fs, dv}
+                            fm = __builtin_amdgcn_fmed3f(dv, fm, -INFINITY);         // min(dv, fm)
+                            rk = lt ? (int)(k + h) : rk;
+                        }
                     }
                 }
-                if (rk >= 0) {
-                    long long rid = sm.pid[rk];
-                    if (tie) {  // some other staged point of this wave's share is exactly as far: lowest id wins
-                        for (unsigned int k = wave * 4; k < cnt; k += 16)
-                            for (int u = 0; u < 4 && k + u < cnt; ++u) {
-                                const double dx = ax - sm.px[k + u], dy = ay - sm.py[k + u], dz = az - sm.pz[k + u];
-                                if ((dx * dx + dy * dy) + dz * dz == rd2 && sm.pid[k + u] < rid) { rid = sm.pid[k + u]; rk = (int)(k + u); }
-                            }
-                    }
-                    if (better(rd2, rid, bd2, bid)) { bd2 = rd2; bid = rid; bpos = sm.ppos[rk]; }
-                }
+                if (rk >= 0) bpos = sm.ppos[rk];
                 __syncthreads();
             }
         }
+        sm.m_m[wave][lane] = fm;
+        sm.m_s[wave][lane] = fs;
+    } else {
+        sm.m_m[wave][lane] = INFINITY;
+        sm.m_s[wave][lane] = INFINITY;
     }
     PH_STAMP(4);
-    // ---- merge the four waves' results per query
-    sm.m_d2[wave][lane] = bd2;
-    sm.m_id[wave][lane] = (bid == ID_NONE) ? 0x7fffffff : (int)bid;
+    // ---- merge the four waves' results per query, then verify in binary64
     sm.m_pos[wave][lane] = bpos;
     __syncthreads();
     unsigned int n_unres = 0;
     if (wave == 0) {
         bool unres = false;
         if (qvalid) {
+            float M = sm.m_m[0][lane], S = sm.m_s[0][lane];
 #pragma unroll
             for (int w = 1; w < 4; ++w) {
-                const double od2 = sm.m_d2[w][lane];
-                const long long oid = sm.m_id[w][lane];
-                if (sm.m_pos[w][lane] != POS_NONE && better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; bpos = sm.m_pos[w][lane]; }
+                const float mw = sm.m_m[w][lane], sw = sm.m_s[w][lane];
+                S = fminf(fmaxf(M, mw), fminf(S, sw));
+                if (mw < M) { M = mw; bpos = sm.m_pos[w][lane]; }
+            }
+            bool ambiguous = false;
+            if (staged && bpos != POS_NONE) {
+                const pcr_pt b = gv.pts[bpos];
+                bd2 = dist2(ax, ay, az, b);  // exact, direct form
+                bid = b.id;
+                // coordinate error of the filter: |local coordinate| <= R, binary32 conversion + subtraction
+                const double cellL = gv.cell0 * (double)(1ll << (2 * level));
+                const double R = 0.5 * cellL * (double)max(sm.dims[0], max(sm.dims[1], sm.dims[2]));
+                const double e = 8.0 * 5.9604644775390625e-08 * R;
+                const double dhi = sqrt((double)M * (1.0 + 1e-6)) + e;
+                const double U = (dhi + e) * (dhi + e) * (1.0 + 1e-6);
+                ambiguous = (double)S <= U;
             }
             if (clamped || !staged) {
                 unres = true;  // nothing usable is known about this query yet
@@ -297,7 +323,7 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
                 }
                 db = fmax(db - cell * 1e-9, 0.0);
                 const double bound2 = gated ? fmin(bd2, max_d2) : bd2;
-                if (bound2 <= db * db) {  // the bound ball lies inside the staged box: exact
+                if (bound2 <= db * db && !ambiguous) {  // the bound ball lies inside the staged box: exact
                     res_pos[qi] = bpos;
                     if (res_d2) res_d2[qi] = bd2;
                 } else {
