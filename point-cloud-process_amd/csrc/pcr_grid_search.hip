@@ -383,16 +383,114 @@ __device__ static inline double wave_min(double v) {
     return v;
 }
 
+struct hard_lds {
+    hard_entry stack[HARD_STACK];
+    unsigned int fl_off[64], fl_start[64];  // flattened scan directory: exclusive point offset / start of every small cell
+};
+
+// One step of the descent.  Every lane holds (at most) one candidate cell.  Cells that are small (or
+// cannot be split further) are read NOW, all together: their ranges are concatenated and the 64 lanes
+// stride over the concatenation, so the reads of a step are independent of each other (one memory round
+// trip instead of one per cell).  Cells that are still big are pushed for a later split, nearest last.
+__device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L, int& sp, int lane, bool valid, unsigned int s, unsigned int e,
+                                            unsigned int X, unsigned int Y, unsigned int Z, int lvl, double bdist, double ax, double ay,
+                                            double az, double& bd2, long long& bid, unsigned int& bpos, double& bound2, unsigned int& n_pts) {
+    const unsigned int cnt = e - s;
+    const bool small = valid && (lvl == 0 || cnt <= HARD_SCAN_T);
+    const unsigned long long m_small = __ballot(small);
+    if (m_small) {
+        // exclusive prefix of the small cells' sizes over the lanes
+        unsigned int inc = small ? cnt : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        const unsigned int total = __shfl(inc, 63, 64);
+        const int n_small = __popcll(m_small);
+        if (small) {
+            const int r = __popcll(m_small & ((1ull << lane) - 1ull));
+            L->fl_off[r] = inc - cnt;
+            L->fl_start[r] = s;
+        }
+        n_pts += total;
+        for (unsigned int t0 = lane; t0 < total; t0 += 128) {
+            // two independent reads per trip
+            unsigned int jj[2];
+            bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned int t = t0 + 64 * u;
+                ok[u] = t < total;
+                int lo = 0, hi = n_small - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (L->fl_off[mid] <= t) lo = mid;
+                    else hi = mid - 1;
+                }
+                jj[u] = L->fl_start[lo] + (t - L->fl_off[lo]);
+            }
+            pcr_pt b0, b1;
+            if (ok[0]) b0 = gv.pts[jj[0]];
+            if (ok[1]) b1 = gv.pts[jj[1]];
+            if (ok[0]) {
+                const double d2 = dist2(ax, ay, az, b0);
+                if (better(d2, b0.id, bd2, bid)) { bd2 = d2; bid = b0.id; bpos = jj[0]; }
+            }
+            if (ok[1]) {
+                const double d2 = dist2(ax, ay, az, b1);
+                if (better(d2, b1.id, bd2, bid)) { bd2 = d2; bid = b1.id; bpos = jj[1]; }
+            }
+        }
+        double m = bd2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+        bound2 = fmin(bound2, m);
+    }
+    // big cells: push (far ones first so that the nearest is split first); without room they are read whole
+    const bool big = valid && !small && bdist <= bound2;
+    const unsigned long long m_far = __ballot(big && bdist > 0.0), m_near = __ballot(big && !(bdist > 0.0));
+    const int n_big = __popcll(m_far) + __popcll(m_near);
+    if (n_big == 0) return;
+    if (sp + n_big <= HARD_STACK) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int slot = -1;
+        if (big && bdist > 0.0) slot = __popcll(m_far & below);
+        else if (big) slot = __popcll(m_far) + __popcll(m_near & below);
+        if (slot >= 0) {
+            hard_entry en;
+            en.start = s; en.end = e; en.x = X; en.y = Y; en.z = Z; en.level = lvl;
+            L->stack[sp + slot] = en;
+        }
+        sp += n_big;
+    } else {
+        unsigned long long mb = m_far | m_near;
+        while (mb) {
+            const int src = __ffsll((long long)mb) - 1;
+            mb &= mb - 1;
+            const unsigned int ss = __shfl(s, src, 64), ee = __shfl(e, src, 64);
+            scan_range(gv.pts, ss + lane, ee, 64, ax, ay, az, bd2, bid, bpos);
+            n_pts += ee - ss;
+        }
+        double m = bd2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+        bound2 = fmin(bound2, m);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ count_p, double max_d2, int gated,
-                 unsigned int* __restrict__ res_pos, double* __restrict__ res_d2) {
-    __shared__ hard_entry s_stack[4][HARD_STACK];
+                 unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, unsigned long long* __restrict__ dbg) {
+    __shared__ hard_lds s_lds[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    hard_entry* stack = s_stack[wave];
+    hard_lds* L = &s_lds[wave];
     const unsigned int count = *count_p;
     const int top = gv.levels - 1;
     for (unsigned int w = blockIdx.x * 4 + wave; w < count; w += gridDim.x * 4) {
         const work_item it = list[w];
+        const unsigned long long h_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+        unsigned int h_steps = 0, h_pts = 0;
         const double ax = it.ax, ay = it.ay, az = it.az;
         double bd2 = DBL_MAX;
         long long bid = ID_NONE;
@@ -415,85 +513,84 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
                 bound2 = fmin(bound2, wave_min(bd2));
             }
         }
-        // start level: the smallest one whose 3x3x3 block covers the bound ball
-        int s_level = -1;
-        if (!clamped && bound2 < DBL_MAX) {
-            double c = gv.cell0;
-            for (int l = 0; l <= top; ++l) {
+        // Level schedule.  With a real candidate in hand the search starts at the smallest level whose
+        // 3x3x3 block covers the bound ball.  Without one (only the gate, or nothing, bounds the search)
+        // it starts at level 0 and grows: the first candidate found shrinks the ball, usually long before
+        // the block would have to cover the whole gate radius in a dense part of the scan.
+        auto level_for = [&](double b2, int from) {
+            double c = gv.cell0 * (double)(1ll << (2 * from));
+            for (int l = from; l <= top; ++l) {
                 const double safe = c * (1.0 - 1e-9);
-                if (safe * safe >= bound2) { s_level = l; break; }
+                if (safe * safe >= b2) return l;
                 c *= 4.0;
             }
-        }
+            return top + 1;  // not even the top level's block covers the ball
+        };
+        const bool have_cand = __any(bd2 < DBL_MAX);
+        int s_level = clamped ? top + 1 : (have_cand ? level_for(bound2, 0) : 0);
+        const int s_level0 = s_level;
         int sp = 0;  // wave-uniform stack pointer
-        {
-            // initial cells: the query's 3x3x3 block at s_level, or the <= 8 root cells that hold the whole target
-            const bool roots = (s_level < 0);
-            const int lvl = roots ? top : s_level;
+        while (s_level <= top) {
+            const int lvl = s_level;
             const double cell = gv.cell0 * (double)(1ll << (2 * lvl));
-            const int b0 = (int)(PCR_COORD_BIAS >> (2 * lvl));
-            int X, Y, Z;
-            bool valid;
-            if (roots) {
-                valid = lane < 8;
-                X = b0 + (lane & 1); Y = b0 + ((lane >> 1) & 1); Z = b0 + ((lane >> 2) & 1);
-            } else {
-                valid = lane < 27;
-                X = (cx >> (2 * lvl)) + (lane % 3 - 1);
-                Y = (cy >> (2 * lvl)) + ((lane / 3) % 3 - 1);
-                Z = (cz >> (2 * lvl)) + (lane / 9 - 1);
-                const int lim = (int)(PCR_COORD_MAX >> (2 * lvl));
-                valid = valid && X >= 0 && Y >= 0 && Z >= 0 && X <= lim && Y <= lim && Z <= lim;
-            }
+            bool valid = lane < 27;
+            const int X = (cx >> (2 * lvl)) + (lane % 3 - 1), Y = (cy >> (2 * lvl)) + ((lane / 3) % 3 - 1), Z = (cz >> (2 * lvl)) + (lane / 9 - 1);
+            const int lim = (int)(PCR_COORD_MAX >> (2 * lvl));
+            valid = valid && X >= 0 && Y >= 0 && Z >= 0 && X <= lim && Y <= lim && Z <= lim;
             unsigned int s = 0, e = 0;
             double bdist = 0.0;
             if (valid) {
                 bdist = box_dist2(gv, lvl, cell, (unsigned int)X, (unsigned int)Y, (unsigned int)Z, ax, ay, az);
                 valid = bdist <= bound2 && lookup_cell(gv.table[lvl], gv.mask[lvl], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &s, &e);
             }
-            // far cells first, the cell containing the query last (popped first)
-            const unsigned long long m_far = __ballot(valid && bdist > 0.0);
-            const unsigned long long m_near = __ballot(valid && !(bdist > 0.0));
-            const unsigned long long below = (1ull << lane) - 1ull;
-            int slot = -1;
-            if (valid && bdist > 0.0) slot = __popcll(m_far & below);
-            else if (valid) slot = __popcll(m_far) + __popcll(m_near & below);
-            if (slot >= 0 && slot < HARD_STACK) {
-                hard_entry en;
-                en.start = s; en.end = e; en.x = (unsigned int)X; en.y = (unsigned int)Y; en.z = (unsigned int)Z; en.level = lvl;
-                stack[slot] = en;
-            }
-            sp = __popcll(m_far) + __popcll(m_near);
-        }
-        while (sp > 0) {
-            --sp;
-            const hard_entry en = stack[sp];  // same address in every lane: LDS broadcast
-            const double cell = gv.cell0 * (double)(1ll << (2 * en.level));
-            if (box_dist2(gv, en.level, cell, en.x, en.y, en.z, ax, ay, az) > bound2) continue;
-            const unsigned int cnt = en.end - en.start;
-            const bool room = sp + 64 <= HARD_STACK;
-            if (en.level == 0 || cnt <= HARD_SCAN_T || !room) {
-                scan_range(gv.pts, en.start + lane, en.end, 64, ax, ay, az, bd2, bid, bpos);
-                bound2 = fmin(bound2, wave_min(bd2));
-            } else {
-                // one child per lane: box test against the bound, probe, push the survivors
+            hard_disperse(gv, L, sp, lane, valid, s, e, (unsigned int)X, (unsigned int)Y, (unsigned int)Z, lvl, bdist, ax, ay, az, bd2, bid, bpos,
+                          bound2, h_pts);
+            ++h_steps;
+            while (sp > 0) {
+                --sp;
+                const hard_entry en = L->stack[sp];  // same address in every lane: LDS broadcast
+                const double ecell = gv.cell0 * (double)(1ll << (2 * en.level));
+                if (box_dist2(gv, en.level, ecell, en.x, en.y, en.z, ax, ay, az) > bound2) continue;
+                // split: one child per lane, box test against the bound, probe
                 const int cl = en.level - 1;
-                const unsigned int X = en.x * 4u + (lane & 3), Y = en.y * 4u + ((lane >> 2) & 3), Z = en.z * 4u + (lane >> 4);
-                const double bdist = box_dist2(gv, cl, cell * 0.25, X, Y, Z, ax, ay, az);
-                unsigned int s = 0, e = 0;
-                const bool valid = bdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], X, Y, Z, &s, &e);
-                const unsigned long long m_far = __ballot(valid && bdist > 0.0);
-                const unsigned long long m_near = __ballot(valid && !(bdist > 0.0));
-                const unsigned long long below = (1ull << lane) - 1ull;
-                int slot = -1;
-                if (valid && bdist > 0.0) slot = __popcll(m_far & below);
-                else if (valid) slot = __popcll(m_far) + __popcll(m_near & below);
-                if (slot >= 0) {
-                    hard_entry ch;
-                    ch.start = s; ch.end = e; ch.x = X; ch.y = Y; ch.z = Z; ch.level = cl;
-                    stack[sp + slot] = ch;
-                }
-                sp += __popcll(m_far) + __popcll(m_near);
+                const unsigned int CX = en.x * 4u + (lane & 3), CY = en.y * 4u + ((lane >> 2) & 3), CZ = en.z * 4u + (lane >> 4);
+                const double cdist = box_dist2(gv, cl, ecell * 0.25, CX, CY, CZ, ax, ay, az);
+                unsigned int cs = 0, ce = 0;
+                const bool cvalid = cdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], CX, CY, CZ, &cs, &ce);
+                hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+                ++h_steps;
+            }
+            const double safe = cell * (1.0 - 1e-9);
+            if (safe * safe >= bound2) break;  // the block just searched covers the bound ball: exact
+            s_level = (bound2 < DBL_MAX) ? level_for(bound2, lvl + 1) : lvl + 1;
+        }
+        if (s_level > top) {
+            // the ball is not covered by any level's 3x3x3 block (query far outside the grid, or no bound at all):
+            // descend from the <= 8 root cells that hold the whole target
+            const double cell = gv.cell0 * (double)(1ll << (2 * top));
+            const int b0 = (int)(PCR_COORD_BIAS >> (2 * top));
+            bool valid = lane < 8;
+            const unsigned int X = b0 + (lane & 1), Y = b0 + ((lane >> 1) & 1), Z = b0 + ((lane >> 2) & 1);
+            unsigned int s = 0, e = 0;
+            double bdist = 0.0;
+            if (valid) {
+                bdist = box_dist2(gv, top, cell, X, Y, Z, ax, ay, az);
+                valid = bdist <= bound2 && lookup_cell(gv.table[top], gv.mask[top], X, Y, Z, &s, &e);
+            }
+            hard_disperse(gv, L, sp, lane, valid, s, e, X, Y, Z, top, bdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+            ++h_steps;
+            while (sp > 0) {
+                --sp;
+                const hard_entry en = L->stack[sp];
+                const double ecell = gv.cell0 * (double)(1ll << (2 * en.level));
+                if (box_dist2(gv, en.level, ecell, en.x, en.y, en.z, ax, ay, az) > bound2) continue;
+                const int cl = en.level - 1;
+                const unsigned int CX = en.x * 4u + (lane & 3), CY = en.y * 4u + ((lane >> 2) & 3), CZ = en.z * 4u + (lane >> 4);
+                const double cdist = box_dist2(gv, cl, ecell * 0.25, CX, CY, CZ, ax, ay, az);
+                unsigned int cs = 0, ce = 0;
+                const bool cvalid = cdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], CX, CY, CZ, &cs, &ce);
+                hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+                ++h_steps;
             }
         }
 #pragma unroll
@@ -506,6 +603,12 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
         if (lane == 0) {
             res_pos[it.qi] = bpos;
             if (res_d2) res_d2[it.qi] = bd2;
+            if (dbg && w < 60000) {
+                dbg[(1 << 17) + w * 4 + 0] = __builtin_amdgcn_s_memtime() - h_t0;
+                dbg[(1 << 17) + w * 4 + 1] = ((unsigned long long)h_steps << 32);
+                dbg[(1 << 17) + w * 4 + 2] = h_pts;
+                dbg[(1 << 17) + w * 4 + 3] = (unsigned long long)(it.best_pos != POS_NONE) | ((unsigned long long)(s_level0 + 1) << 8);
+            }
         }
     }
 }
@@ -668,7 +771,7 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc,
     const long long want = (nq + 3) / 4;
     const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
     hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, ctx->stream, idx->view, (const work_item*)sc->hard_list,
-                       (const unsigned int*)sc->hard_count, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2);
+                       (const unsigned int*)sc->hard_count, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }

@@ -34,3 +34,14 @@ names = ["load+box", "lookups", "scan", "staging", "eval", "merge+lists"]
 print("single-round tiles (P<=512): n=%d, median P=%.0f" % (one.sum(), np.median(P[one])))
 for k, nm in enumerate(names):
     print("   %-12s median %7.0f  p90 %7.0f cycles" % (nm, np.median(d[one, k]), np.percentile(d[one, k], 90)))
+# hard-stage items
+hb = np.zeros((1 << 17) + 60000 * 4, dtype=np.uint64)
+L.check(L.lib().pcr_debug_read(ctx.handle, hb.ctypes.data_as(C.POINTER(C.c_uint64)), hb.size))
+h = hb[(1 << 17):].reshape(-1, 4)
+h = h[h[:, 0] > 0]
+hc = h[:, 0].astype(np.float64); sc_ = (h[:, 1] >> np.uint64(32)).astype(int); ex = (h[:, 1] & np.uint64(0xffffffff)).astype(int); pts = h[:, 2].astype(int)
+known = (h[:, 3] & np.uint64(1)).astype(bool); sl = ((h[:, 3] >> np.uint64(8)).astype(int) - 1)
+print("hard items", len(h), "cycles pct 50/90/99/max", np.percentile(hc, [50, 90, 99, 100]), "sum", hc.sum())
+print("  scans/item mean %.1f max %d | expands/item mean %.1f max %d | pts scanned/item mean %.0f max %d" % (sc_.mean(), sc_.max(), ex.mean(), ex.max(), pts.mean(), pts.max()))
+print("  with prior bound: %d (median cycles %.0f) | without: %d (median cycles %.0f)" % (known.sum(), np.median(hc[known]), (~known).sum(), np.median(hc[~known]) if (~known).any() else 0))
+print("  start level histogram", np.bincount(sl + 1))
