@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nn", default="grid", choices=["grid", "brute"])
     ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--cell", type=float, default=0.0, help="level-0 cell size of the grid index in metres (0 = automatic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-brute", action="store_true", help="skip the brute-force MFMA leg")
     a = ap.parse_args()
@@ -128,7 +129,7 @@ def main():
 
     # every rank registers its own pair (different seed); same size => weak scaling
     src, tgt, T_true = syn.perturbed_pair(a.points, seed=rank)
-    index = pkg.TargetIndex(pkg.DeviceCloud.upload(tgt, ctx), kind=a.nn, ctx=ctx)
+    index = pkg.TargetIndex(pkg.DeviceCloud.upload(tgt, ctx), kind=a.nn, cell=a.cell, ctx=ctx)
     ctx.sync()
 
     def barrier():

@@ -24,11 +24,12 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int BR_NT = 4;          // query tiles (of 16) per wave -> 64 queries per wave
 constexpr int BR_WAVES = 4;       // waves per block
 constexpr int BR_QPB = BR_NT * 16 * BR_WAVES;  // queries per block = 256
+constexpr int BR_PAD = 8;         // never-winning padding tiles behind the last real one (unconditional prefetch)
 
 __global__ void brute_prep_kernel(const pcr_pt* __restrict__ pts, long long n, long long n_tiles, double ox, double oy, double oz,
                                   double* __restrict__ mfma_a) {
     long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_tiles * 64) return;
+    if (g >= (n_tiles + BR_PAD) * 64) return;
     long long t = g >> 6;
     int l = (int)(g & 63);
     int i = l & 15, k = l >> 4;
@@ -56,6 +57,10 @@ struct brute_cand {  // per (target split, query): best candidate of that split
     int id;
     int pad;
 };
+
+// plain v_min_f64: this file is compiled with -fno-honor-nans so fmin() does not canonicalise its inputs
+// (an inline-asm v_min_f64 is not an option here: hipcc inserts no MFMA->VALU wait states for asm operands).
+__device__ static inline double bvmin(double a, double b) { return fmin(a, b); }
 
 __device__ static inline double dist2_pt(double ax, double ay, double az, const pcr_pt& b) {
     double dx = ax - b.x, dy = ay - b.y, dz = az - b.z;
@@ -101,16 +106,50 @@ brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tg
     const long long t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
     if (t0 < t1) {
-        double a_cur = mfma_a[t0 * 64 + lane];
-        for (long long t = t0; t < t1; ++t) {
-            double a_nxt = (t + 1 < t1) ? mfma_a[(t + 1) * 64 + lane] : 0.0;
+        // Software pipeline.  (1) A operands are fetched BR_PF tiles ahead (one tile is only 4 x 64 MFMA cycles of
+        // work, less than an L2 round trip).  (2) The 4 MFMAs of tile t are issued BEFORE the min/argmin epilogue
+        // of tile t-1, so the VALU work runs in the shadow of the matrix pipe.  The epilogue uses plain v_min_f64
+        // (fmin() would add two canonicalising v_max_f64 per call).
+        // mfma_a is padded with BR_PAD never-winning tiles, so every load below is unconditional: the compiler can
+        // then wait with a counted vmcnt(BR_PF) for the tile it needs instead of draining the prefetch.
+        constexpr int BR_PF = 4;
+        double a_cur[BR_PF], a_nxt[BR_PF];
 #pragma unroll
-            for (int tt = 0; tt < BR_NT; ++tt) {
-                v4f64 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur, bq[tt], zero, 0, 0, 0);
-                double m = fmin(fmin(acc[0], acc[1]), fmin(acc[2], acc[3]));
-                if (m < best[tt]) { best[tt] = m; btile[tt] = (int)t; }
+        for (int i = 0; i < BR_PF; ++i) a_cur[i] = mfma_a[(t0 + i) * 64 + lane];
+        const v4f64 never = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
+        v4f64 acc[BR_NT];
+#pragma unroll
+        for (int tt = 0; tt < BR_NT; ++tt) acc[tt] = never;
+        for (long long tb = t0; tb < t1; tb += BR_PF) {
+#pragma unroll
+            for (int i = 0; i < BR_PF; ++i) a_nxt[i] = mfma_a[(tb + BR_PF + i) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch up here: hipcc otherwise sinks it next to its first use
+#pragma unroll
+            for (int i = 0; i < BR_PF; ++i) {
+                // tiles past t1 inside the last group belong to the next split or are padding: harmless to look at
+                v4f64 cur[BR_NT];
+#pragma unroll
+                for (int tt = 0; tt < BR_NT; ++tt) cur[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[i], bq[tt], zero, 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < BR_NT; ++tt) {
+                    const double m = bvmin(bvmin(acc[tt][0], acc[tt][1]), bvmin(acc[tt][2], acc[tt][3]));
+                    const bool lt = m < best[tt];
+                    best[tt] = lt ? m : best[tt];
+                    btile[tt] = lt ? (int)(tb + i - 1) : btile[tt];
+                }
+#pragma unroll
+                for (int tt = 0; tt < BR_NT; ++tt) acc[tt] = cur[tt];
             }
-            a_cur = a_nxt;
+#pragma unroll
+            for (int i = 0; i < BR_PF; ++i) a_cur[i] = a_nxt[i];
+        }
+        const long long t_last = t0 + ((t1 - t0 + BR_PF - 1) / BR_PF) * BR_PF - 1;
+#pragma unroll
+        for (int tt = 0; tt < BR_NT; ++tt) {  // epilogue of the last tile
+            const double m = bvmin(bvmin(acc[tt][0], acc[tt][1]), bvmin(acc[tt][2], acc[tt][3]));
+            const bool lt = m < best[tt];
+            best[tt] = lt ? m : best[tt];
+            btile[tt] = lt ? (int)t_last : btile[tt];
         }
     }
     // exact re-evaluation of each lane's 4 candidate rows, then merge the 4 row groups of a query
@@ -242,11 +281,11 @@ int pcr_brute_build(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_index* idx) {
     const long long n = tgt->n;
     idx->n_tiles = (n + 15) / 16;
     int rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 64 * idx->n_tiles, (void**)&idx->mfma_a))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 64 * (idx->n_tiles + BR_PAD), (void**)&idx->mfma_a))) return rc;
     if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&idx->plain))) return rc;
     // row order (record id == position), whatever order the cloud currently has on the device
     hipLaunchKernelGGL(brute_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)tgt->d, n, idx->plain);
-    const long long threads = idx->n_tiles * 64;
+    const long long threads = (idx->n_tiles + BR_PAD) * 64;
     hipLaunchKernelGGL(brute_prep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)idx->plain, n,
                        (long long)idx->n_tiles, idx->view.origin[0], idx->view.origin[1], idx->view.origin[2], idx->mfma_a);
     PCR_HIP(ctx, hipGetLastError());
@@ -254,7 +293,7 @@ int pcr_brute_build(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_index* idx) {
 }
 
 void pcr_brute_free(pcr_ctx* ctx, pcr_index* idx) {
-    pcr_dev_free(ctx, idx->mfma_a, sizeof(double) * 64 * idx->n_tiles);
+    pcr_dev_free(ctx, idx->mfma_a, sizeof(double) * 64 * (idx->n_tiles + BR_PAD));
     pcr_dev_free(ctx, idx->plain, sizeof(pcr_pt) * idx->n);
     idx->mfma_a = nullptr;
     idx->plain = nullptr;

@@ -67,7 +67,7 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     if (!c) return PCR_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (auto& b : c->free_list) hipFree(b.p);
+    for (void* a : c->arenas) hipFree(a);
     if (c->d_partials) hipFree(c->d_partials);
     if (c->d_counters) hipFree(c->d_counters);
     if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -153,6 +153,12 @@ void pcr_prof_finish(pcr_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------ memory
+// Device memory comes from a few large arenas (256 MiB hipMalloc each, so every buffer of the path sits in
+// 2-MiB-fragment mappings: with one hipMalloc per buffer the scattered 16..64-byte reads of the search kernels
+// paid a TLB walk on most accesses).  Blocks are recycled through a size-matched free list; arenas are only
+// released with the context.
+static const size_t PCR_ARENA_BYTES = 256ull << 20;
+
 int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
@@ -166,17 +172,23 @@ int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out) {
         ctx->free_list.erase(ctx->free_list.begin() + best);
         return PCR_OK;
     }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) {
-        // drop the cache and retry once
-        for (auto& b : ctx->free_list) hipFree(b.p);
-        ctx->free_list.clear();
-        e = hipMalloc(out, bytes);
+    if (ctx->arenas.empty() || ctx->arena_used + bytes > ctx->arena_cap) {
+        const size_t cap = bytes > PCR_ARENA_BYTES ? bytes : PCR_ARENA_BYTES;
+        void* base = nullptr;
+        hipError_t e = hipMalloc(&base, cap);
         if (e != hipSuccess) {
-            ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+            ctx->last_error = std::string("hipMalloc(arena): ") + hipGetErrorString(e);
             return PCR_E_NOMEM;
         }
+        // what is left of the previous arena stays usable through the free list
+        if (!ctx->arenas.empty() && ctx->arena_cap > ctx->arena_used)
+            ctx->free_list.push_back({(char*)ctx->arenas.back() + ctx->arena_used, ctx->arena_cap - ctx->arena_used});
+        ctx->arenas.push_back(base);
+        ctx->arena_cap = cap;
+        ctx->arena_used = 0;
     }
+    *out = (char*)ctx->arenas.back() + ctx->arena_used;
+    ctx->arena_used += bytes;
     return PCR_OK;
 }
 
@@ -184,13 +196,7 @@ void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes) {
     if (!p) return;
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
-    // frees are stream-ordered with later allocations because every user of the
-    // block runs on ctx->stream
-    if (ctx->free_list.size() >= 64) {
-        hipStreamSynchronize(ctx->stream);
-        hipFree(ctx->free_list.front().p);
-        ctx->free_list.erase(ctx->free_list.begin());
-    }
+    // frees are stream-ordered with later allocations because every user of the block runs on ctx->stream
     ctx->free_list.push_back({p, bytes});
 }
 

@@ -74,6 +74,8 @@ struct pcr_ctx {
     // grow-only caching allocator (device) keyed by size; avoids hipMalloc in the ICP loop
     struct blk { void* p; size_t sz; };
     std::vector<blk> free_list;
+    std::vector<void*> arenas;   // 256-MiB hipMalloc chunks the blocks are carved from
+    size_t arena_cap = 0, arena_used = 0;
     // pinned host scratch for the per-iteration moment read-back
     double* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
