@@ -28,8 +28,8 @@
 constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
 constexpr int T_MAXC = 1024;                // cells in a tile box
 constexpr int T_CPT = T_MAXC / 256;         // cells looked up per thread
-constexpr int T_PMAX = 1024;                // points staged per round
-constexpr unsigned int T_PCAP = 2 * T_PMAX;   // tiles with more candidate points than this go per-query
+constexpr int T_PMAX = 512;                 // points staged per round
+constexpr unsigned int T_PCAP = 4 * T_PMAX;   // tiles with more candidate points than this go per-query
 constexpr unsigned int HARD_SCAN_T = 192;   // the hard stage scans cells up to this size, descends into bigger ones
 constexpr int HARD_STACK = 160;
 constexpr long long ID_NONE = 0x7fffffffffffffffll;
