@@ -49,7 +49,8 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
     hipEventCreate(&c->ev2);
     hipEventCreate(&c->ev3);
     c->h_pinned_bytes = 4096;
-    if (hipHostMalloc((void**)&c->h_pinned, c->h_pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+    c->zero_copy = getenv("PCR_NO_ZEROCOPY") == nullptr;
+    if (hipHostMalloc((void**)&c->h_pinned, c->h_pinned_bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         delete c;
         return PCR_E_NOMEM;
     }

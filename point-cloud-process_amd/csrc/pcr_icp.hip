@@ -168,10 +168,12 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
         pcr_xform_from_T(T_cur, &x);
         // main.py:110 / icp_template.py:195: the source is transformed in place, fused into the pass
         if (ctx->profile) PCR_HIP(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-        rc = icp_pass(ctx, index, source, &x, params->max_d2, 1, d_mom);
+        // zero-copy read-back: the last block of the pass writes the 160 bytes of moments straight into pinned,
+        // device-mapped host memory (no copy command in the stream, one wait per iteration)
+        rc = icp_pass(ctx, index, source, &x, params->max_d2, 1, ctx->zero_copy ? ctx->h_pinned : d_mom);
         if (rc) break;
         if (ctx->profile) PCR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
-        PCR_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_mom, sizeof(double) * PCR_NMOM, hipMemcpyDeviceToHost, ctx->stream));
+        if (!ctx->zero_copy) PCR_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_mom, sizeof(double) * PCR_NMOM, hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         float ms = 0;
         if (ctx->profile) hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3);  // per-pass kernel time only while profiling

@@ -79,6 +79,7 @@ struct pcr_ctx {
     // pinned host scratch for the per-iteration moment read-back
     double* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
+    bool zero_copy = true;  // kernels write small results straight into h_pinned (PCR_NO_ZEROCOPY=1 disables)
     // device scratch for per-block partial moments
     double* d_partials = nullptr;
     size_t d_partials_bytes = 0;
