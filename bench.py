@@ -178,8 +178,14 @@ def main():
         dom_s = kern[dom] * 1e-6
         if a.nn == "grid":
             algo_bytes = GRID_BYTES_PER_CORR * n_src
+            traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                traffic = pmc["kernels"][dom].get("hbm_bytes") if a.points == N_POINTS else None
+            except Exception:
+                traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": algo_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo_bytes / dom_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": algo_bytes / dom_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                         "note": "working set (2 x 3.8 MB) is L2/MALL resident; this kernel is latency/issue bound, not HBM bound"}
         else:
             flops = 8.0 * n_src * a.points
