@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nn", default="grid", choices=["grid", "brute"])
     ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default LOCAL_RANK)")
     ap.add_argument("--cell", type=float, default=0.0, help="level-0 cell size of the grid index in metres (0 = automatic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-brute", action="store_true", help="skip the brute-force MFMA leg")
@@ -121,10 +123,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dev_id = a.device if a.device >= 0 else local_rank
+        torch.cuda.set_device(dev_id)
+        if a.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_id))
+        else:
+            dist.init_process_group(backend=a.dist_backend)
+    dev_id = a.device if a.device >= 0 else local_rank
+    tdev = f"cuda:{dev_id}" if (world == 1 or a.dist_backend == "nccl") else "cpu"
     pkg = importlib.import_module("point-cloud-process_amd")
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(dev_id)
     syn = pkg.synthetic
 
     # every rank registers its own pair (different seed); same size => weak scaling
@@ -144,7 +152,7 @@ def main():
     r = run_icp_steps(pkg, index, src, a.steps, ctx)
     # result gather: 16 doubles + iters + n_assoc per rank (RCCL all_gather), inside the timed region
     if dist is not None:
-        rec = torch.zeros(18, dtype=torch.float64, device=f"cuda:{local_rank}")
+        rec = torch.zeros(18, dtype=torch.float64, device=tdev)
         rec[:16] = torch.from_numpy(r["T_total"].reshape(16))
         rec[16] = r["iters"]
         rec[17] = r["n_assoc"]
@@ -153,7 +161,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
