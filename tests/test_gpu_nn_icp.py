@@ -165,3 +165,33 @@ def test_procrustes_and_pose_utils(pcp):
     for T, tq in zip(p["T"], p["tq"]):
         assert np.allclose(pcp.homo2tq(T), tq, rtol=0, atol=1e-15)
         assert np.allclose(pcp.rotmat2quaternion(T[:3, :3]), tq[3:], rtol=0, atol=1e-15)
+
+
+def test_nn1_far_from_origin_and_odd_sizes(pcp, oracle, syn):
+    """The tile stage filters in binary32 about the tile centre: absolute coordinates of 1e6 m (UTM-like),
+    sizes that are not multiples of the 64-query tile, and query == target (d = 0) must stay exact."""
+    rng = np.random.default_rng(8)
+    off = np.array([4.0e5, 5.5e6, 300.0])
+    tgt = syn.kitti_like_scan(30011, seed=21).astype(np.float64) + off
+    src = syn.kitti_like_scan(10007, seed=22).astype(np.float64) + off + rng.normal(0, 0.02, (10007, 3))
+    index = pcp.TargetIndex(tgt, kind="grid")
+    idx, d2 = index.nn1(src)  # no gate: every query must resolve
+    oi, od2, margin = oracle.nn1_exact(src, tgt)
+    assert np.array_equal(d2, od2)
+    clear = margin > TIE_MARGIN
+    assert np.array_equal(idx[clear], oi[clear])
+    for n in (1, 63, 65):
+        i2, dd = index.nn1(tgt[:n])  # queries that ARE targets
+        assert np.array_equal(i2, np.arange(n)) and (dd == 0).all()
+
+
+def test_nn1_dense_volume_and_clustered_duplicates(pcp, oracle):
+    rng = np.random.default_rng(9)
+    tgt = rng.uniform(0, 2.0, (40000, 3))
+    tgt[5000:5200] = tgt[100]  # 200 exact duplicates of one point: ties must resolve to the lowest index
+    q = rng.uniform(-0.1, 2.1, (5000, 3))
+    q[:50] = tgt[100] + rng.normal(0, 1e-4, (50, 3))
+    idx, d2 = pcp.TargetIndex(tgt, kind="grid").nn1(q)
+    bi, bd2 = oracle.nn1_bruteforce(q, tgt)
+    assert np.array_equal(d2, bd2)
+    assert np.array_equal(idx, bi)  # np.argmin also returns the first (lowest) index on ties
