@@ -351,6 +351,52 @@ def gen_icp(syn, big=False):
     print("pose/procrustes goldens written")
 
 
+# --------------------------------------------------------------------------
+# G6: evaluator (Registration/registration_dataset/evaluate_rt.py)
+# --------------------------------------------------------------------------
+def gen_eval(syn):
+    install_stubs()
+    ev = import_ref(os.path.join("Registration", "registration_dataset"), "evaluate_rt")
+    rng = np.random.default_rng(61)
+    n = 40
+    rows_gt, rows_pr = [], []
+    Pg, Pp = [], []
+    for i in range(n):
+        Tg = syn.rigid_transform(rng.normal(size=3), rng.uniform(-3, 3), rng.uniform(-20, 20, 3))
+        # predictions: some close, some off in translation, some off in rotation
+        kind = i % 4
+        dang = {0: 0.01, 1: 0.02, 2: 0.2, 3: 0.01}[kind]
+        dt = {0: 0.1, 1: 3.0, 2: 0.1, 3: 1.5}[kind]
+        Tp = syn.rigid_transform(rng.normal(size=3), dang, rng.normal(size=3) / np.sqrt(3) * dt) @ Tg
+        Pg.append(Tg)
+        Pp.append(Tp)
+        rows_gt.append([i, 100 + i] + list(ev_tq(Tg)))
+        rows_pr.append([i, 100 + i] + list(ev_tq(Tp)))
+    import tempfile
+
+    hdr = "idx1,idx2,t_x,t_y,t_z,q_w,q_x,q_y,q_z"
+    d = tempfile.mkdtemp()
+    fg, fp = os.path.join(d, "gt.txt"), os.path.join(d, "pred.txt")
+    np.savetxt(fg, np.array(rows_gt), delimiter=",", header=hdr, comments="", fmt="%i,%i" + ",%.12f" * 7)
+    np.savetxt(fp, np.array(rows_pr), delimiter=",", header=hdr, fmt="%i,%i" + ",%f" * 7)  # np.savetxt default "# " header, like main.py
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rate, rte, rre = ev.evaluate_rt(fg, fp)
+    diffs = np.array([ev.get_P_diff(a, b) for a, b in zip(Pp, Pg)])
+    succ = np.array([ev.is_registration_successful(a, b)[0] for a, b in zip(Pp, Pg)])
+    np.savez_compressed(os.path.join(GOLD, "evaluate_rt.npz"), P_gt=np.array(Pg), P_pred=np.array(Pp), diffs=diffs, success=succ,
+                        summary=np.array([rate, rte, rre]), gt_text=np.array(open(fg).read()), pred_text=np.array(open(fp).read()))
+    print("evaluate_rt: rate %.4f rte %.4f rre %.4f" % (rate, rte, rre))
+
+
+def ev_tq(T):
+    """t, q (w first) of a pose for the result files (same convention as main.py:170-174, via scipy)."""
+    from scipy.spatial.transform import Rotation
+
+    q = Rotation.from_matrix(T[:3, :3]).as_quat()  # x,y,z,w
+    return T[0, 3], T[1, 3], T[2, 3], q[3], q[0], q[1], q[2]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also run the N=20000 literal ICP (~40 s, ~10 GB RSS)")
@@ -368,6 +414,8 @@ def main():
         gen_nn_api(syn)
     if a.only in ("", "icp"):
         gen_icp(syn, big=a.big)
+    if a.only in ("", "eval"):
+        gen_eval(syn)
 
 
 if __name__ == "__main__":

@@ -33,5 +33,8 @@ from .kdtree import kdtree_construction, kdtree_knn_search, kdtree_radius_search
 from .octree import octree_construction, octree_knn_search, octree_radius_search, octree_radius_search_fast  # noqa: F401
 from .iss import iss_keypoints  # noqa: F401
 from .batch import register_batch, shard_range  # noqa: F401
+from . import evaluate  # noqa: F401
+from .evaluate import evaluate_rt, get_P_diff, is_registration_successful  # noqa: F401
+from .drivers import read_pair_list, run_registration  # noqa: F401
 
 __version__ = "0.1.0"
