@@ -178,6 +178,20 @@ PCR_API int pcr_voxel_filter_cloud(pcr_ctx* ctx, const pcr_cloud* in, double lea
 PCR_API int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, double gamma21, double gamma32, double nms_radius,
                     int max_keypoints, double* lambdas_out, int32_t* counts_out, int32_t* keypoints_out, int* n_keypoints_out);
 
+/* ---------------------------------------------------------- PCA / normals
+ * pcr_pca: Pca_and_Voxel_filter/pca_normal.py:10-36 PCA(data, sort=True):
+ * eigen-decomposition of np.cov of the cloud (divisor n-1); eigvals_out
+ * descending, eigvecs_out row-major 3x3 whose COLUMNS are the eigenvectors
+ * (sign arbitrary, like LAPACK's in the reference).  mean_out may be NULL.
+ * pcr_normals: pca_normal.py:85-90 -- for every point the eigenvector of the
+ * smallest eigenvalue of the covariance of its k nearest neighbours (the point
+ * itself included, like search_knn_vector_3d on a cloud point); 2 <= k <= 16.
+ * normals_out (n,3) by caller row; eigvals_out (n,3) descending and
+ * neighbours_out (n,k) ascending (distance, index) may be NULL.             */
+PCR_API int pcr_pca(pcr_ctx* ctx, const pcr_cloud* cloud, double eigvals_out[3], double eigvecs_out[9], double mean_out[3]);
+PCR_API int pcr_normals(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double* normals_out, double* eigvals_out,
+                        int32_t* neighbours_out);
+
 /* ------------------------------------------------------------- timing aid
  * HIP-event stopwatch on the ctx stream, for bench.py's roofline figures.   */
 PCR_API int pcr_timer_start(pcr_ctx* ctx);

@@ -284,3 +284,34 @@ def iss_oracle(points, radius=0.5, lambda21=0.5, lambda32=0.5, non_max_radius=0.
         if len(iss) > iss_count:
             break
     return iss, lam, counts
+
+
+# ------------------------------------------------------------ PCA / normals
+def pca(data, sort=True):
+    """Pca_and_Voxel_filter/pca_normal.py:10-36: eigen-decomposition of the sample covariance (divisor N-1)
+    of the (N,3) cloud; eigenvalues descending, eigenvectors as columns.  Pinned by tests/golden/pca_normals.npz."""
+    x = np.asarray(data, dtype=np.float64)
+    c = x - x.mean(axis=0, keepdims=True)            # pca_normal.py:22-23
+    H = c.T @ c / (len(x) - 1)                        # np.cov, pca_normal.py:25
+    w, v = np.linalg.eigh(H)                          # pca_normal.py:27
+    if sort:
+        o = w.argsort()[::-1]                         # pca_normal.py:30-33
+        w, v = w[o], v[:, o]
+    return w, v
+
+
+def normals(points, k=5):
+    """pca_normal.py:85-90: for every point, v[:, 2] of the PCA of its k nearest neighbours (itself included).
+    Returns (normals (N,3), eigenvalues (N,3), neighbours (N,k))."""
+    pts = np.asarray(points, dtype=np.float64)
+    k = min(k, len(pts))
+    nbr = np.empty((len(pts), k), dtype=np.int64)
+    for i, q in enumerate(pts):
+        idx, _ = knn_bruteforce(pts, q, k)
+        nbr[i] = idx
+    out = np.empty((len(pts), 3))
+    evs = np.empty((len(pts), 3))
+    for i in range(len(pts)):
+        w, v = pca(pts[nbr[i]])
+        out[i], evs[i] = v[:, 2], w
+    return out, evs, nbr

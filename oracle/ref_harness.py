@@ -389,6 +389,46 @@ def gen_eval(syn):
     print("evaluate_rt: rate %.4f rte %.4f rre %.4f" % (rate, rte, rre))
 
 
+# --------------------------------------------------------------------------
+# G7: PCA + normals (Pca_and_Voxel_filter/pca_normal.py)
+# --------------------------------------------------------------------------
+def gen_pca(syn):
+    install_stubs()
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    ref = import_ref("Pca_and_Voxel_filter", "pca_normal")
+    o3d = sys.modules["open3d"]
+    out = {}
+    rng = np.random.default_rng(71)
+    clouds = {
+        "object": syn.object_cloud(2000, seed=5),
+        "plane": np.c_[rng.uniform(-1, 1, (500, 2)), np.zeros(500)] @ syn.rigid_transform([1, 2, 3], 0.7, [0, 0, 0])[:3, :3].T,
+        "tiny": rng.normal(size=(6, 3)),
+        "scan": syn.kitti_like_scan(3000, seed=9).astype(np.float64),
+    }
+    for tag, pts in clouds.items():
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        w, v = ref.PCA(pts)                          # pca_normal.py:70
+        # the script body pca_normal.py:83-90 (it lives in main(), so the loop is restated around the reference's PCA)
+        pc = o3d.geometry.PointCloud(pts)
+        tree = o3d.geometry.KDTreeFlann(pc)
+        k = min(5, len(pts))
+        normals, nbrs, evs = [], [], []
+        for point in pts:
+            _, idx, _ = tree.search_knn_vector_3d(point, k)
+            wk, vk = ref.PCA(pts[idx, :])
+            normals.append(vk[:, 2])
+            nbrs.append(idx)
+            evs.append(wk)
+        out[tag + "_pts"] = pts
+        out[tag + "_w"] = w
+        out[tag + "_v"] = v
+        out[tag + "_normals"] = np.array(normals)
+        out[tag + "_nbrs"] = np.array(nbrs, dtype=np.int32)
+        out[tag + "_evs"] = np.array(evs)
+        print("pca %-6s n=%d w=%s" % (tag, len(pts), np.array2string(w, precision=4)))
+    np.savez_compressed(os.path.join(GOLD, "pca_normals.npz"), **out)
+
+
 def ev_tq(T):
     """t, q (w first) of a pose for the result files (same convention as main.py:170-174, via scipy)."""
     from scipy.spatial.transform import Rotation
@@ -416,6 +456,8 @@ def main():
         gen_icp(syn, big=a.big)
     if a.only in ("", "eval"):
         gen_eval(syn)
+    if a.only in ("", "pca"):
+        gen_pca(syn)
 
 
 if __name__ == "__main__":

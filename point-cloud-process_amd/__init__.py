@@ -32,6 +32,7 @@ from .result_set import DistIndex, KNNResultSet, RadiusNNResultSet  # noqa: F401
 from .kdtree import kdtree_construction, kdtree_knn_search, kdtree_radius_search, knn_search_batch, radius_search_batch  # noqa: F401
 from .octree import octree_construction, octree_knn_search, octree_radius_search, octree_radius_search_fast  # noqa: F401
 from .iss import iss_keypoints  # noqa: F401
+from .pca_normal import PCA, estimate_normals  # noqa: F401
 from .batch import register_batch, shard_range  # noqa: F401
 from . import evaluate  # noqa: F401
 from .evaluate import evaluate_rt, get_P_diff, is_registration_successful  # noqa: F401

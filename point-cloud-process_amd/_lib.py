@@ -104,6 +104,8 @@ SIGNATURES = {
     "pcr_voxel_filter": (C.c_int, [_vp, _dp, C.c_int64, C.c_double, C.c_int, C.c_uint64, _dp, _lp]),
     "pcr_voxel_filter_cloud": (C.c_int, [_vp, _vp, C.c_double, C.c_int, C.c_uint64, C.POINTER(_vp)]),
     "pcr_iss": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _ip, _ip, C.POINTER(C.c_int)]),
+    "pcr_pca": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
+    "pcr_normals": (C.c_int, [_vp, _vp, C.c_int, _dp, _dp, _ip]),
     "pcr_debug_read": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int64]),
     "pcr_profile_enable": (C.c_int, [_vp, C.c_int]),
     "pcr_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),

@@ -123,3 +123,15 @@ def test_c_oracle_against_reference_goldens(oracle):
         out = np.zeros(7)
         lib.oc_homo2tq(np.ascontiguousarray(T).ctypes.data_as(dp), out.ctypes.data_as(dp))
         assert np.allclose(out, tq, rtol=0, atol=1e-15)
+
+
+def test_pca_and_normals_match_reference(oracle):
+    from tests.pca_checks import check_normals, check_pca
+
+    g = load_golden("pca_normals.npz")
+    for tag in ("object", "plane", "tiny", "scan"):
+        pts = g[f"{tag}_pts"]
+        w, v = oracle.pca(pts)
+        check_pca(w, v, g[f"{tag}_w"], g[f"{tag}_v"])
+        nrm, evs, nbr = oracle.normals(pts, 5)
+        check_normals(pts, nrm, evs, nbr, g[f"{tag}_normals"], g[f"{tag}_evs"], g[f"{tag}_nbrs"])
