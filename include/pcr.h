@@ -164,7 +164,11 @@ PCR_API int pcr_homo2tq(const double T[16], double out7[7]);
  * pcr_voxel_keys: per-point key h (float64, bit-exact, voxel_filter.py:20-33) and D[3].
  * pcr_voxel_filter: mode 0 = "centroid", 1 = "random" (explicit seed).  Output
  * rows = occupied voxels - 1 (the reference never emits its last group,
- * voxel_filter.py:42-51); out must hold n*3 doubles.                         */
+ * voxel_filter.py:42-51); out must hold n*3 doubles.
+ * mode 2 = Open3D's voxel_down_sample as called at Registration/main.py:35:
+ * origin min - leaf/2, every occupied voxel emitted, centroid = running sum in
+ * input order / count; rows ordered by voxel key (Open3D's order is that of
+ * its hash map and is not part of its contract).                             */
 PCR_API int pcr_voxel_keys(pcr_ctx* ctx, const double* xyz, int64_t n, double leaf, double* h_out, double D_out[3]);
 PCR_API int pcr_voxel_filter(pcr_ctx* ctx, const double* xyz, int64_t n, double leaf, int mode, uint64_t seed,
                              double* out_xyz, int64_t* n_out);
@@ -191,6 +195,47 @@ PCR_API int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, double 
 PCR_API int pcr_pca(pcr_ctx* ctx, const pcr_cloud* cloud, double eigvals_out[3], double eigvecs_out[9], double mean_out[3]);
 PCR_API int pcr_normals(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double* normals_out, double* eigvals_out,
                         int32_t* neighbours_out);
+
+/* ------------------------------------------- global initialisation (next row)
+ * The Open3D stage in front of ICP, Registration/main.py:33-84, and the template
+ * surface icp_template.py:20-41,56-110.  Open3D is absent and unpinned in the
+ * reference; these follow its published behaviour ("parity unpinned").
+ * pcr_normals_hybrid: estimate_normals(KDTreeSearchParamHybrid(radius, max_nn))
+ *   (main.py:39-40): neighbourhood = the <= max_nn nearest points with
+ *   d^2 < radius^2; fewer than 3 -> (0,0,1).  orient != 0 flips every normal
+ *   toward viewpoint[3] (NULL = origin); orient == 0 leaves the solver's sign.
+ * pcr_fpfh: compute_fpfh_feature (main.py:44-46); normals (n,3) by row;
+ *   features_out (n,33) row-major (= Open3D's Feature.data (33,n) column-major).
+ * pcr_feature_match: nearest target row in feature space for every query row
+ *   (find_matchings, icp_template.py:20-41); squared L2, ties to the lowest row.
+ * pcr_ransac: registration_ransac_based_on_feature_matching's loop
+ *   (main.py:73-83) / ransac_init's loop (icp_template.py:88-110) over a given
+ *   correspondence set corr (m,2) of (source row, target row): 3 samples,
+ *   edge-length and distance checkers, Kabsch, inliers counted over corr,
+ *   running best in iteration order with the confidence-based early exit.    */
+typedef struct pcr_ransac_params {
+    int32_t max_iteration;
+    int32_t check_distance;
+    double confidence;
+    double max_distance;
+    double edge_similarity; /* <= 0 switches the edge-length checker off */
+    uint64_t seed;
+    double reserved[4];
+} pcr_ransac_params;
+typedef struct pcr_ransac_result {
+    double T[16];
+    int32_t iterations, n_valid, best_iteration, reserved_i;
+    double corr_fitness, corr_rmse;
+    double reserved[4];
+} pcr_ransac_result;
+PCR_API int pcr_normals_hybrid(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int max_nn, int orient, const double viewpoint[3],
+                               double* normals_out);
+PCR_API int pcr_fpfh(pcr_ctx* ctx, const pcr_cloud* cloud, const double* normals, double radius, int max_nn, double* features_out);
+PCR_API int pcr_feature_match(pcr_ctx* ctx, const double* queries, int64_t nq, const double* targets, int64_t nt, int dim,
+                              int32_t* idx_out, double* d2_out);
+PCR_API int pcr_ransac_default_params(pcr_ransac_params* p);
+PCR_API int pcr_ransac(pcr_ctx* ctx, const pcr_cloud* source, const pcr_cloud* target, const int32_t* corr, int64_t m,
+                       const pcr_ransac_params* params, pcr_ransac_result* result);
 
 /* ------------------------------------------------------------- timing aid
  * HIP-event stopwatch on the ctx stream, for bench.py's roofline figures.   */

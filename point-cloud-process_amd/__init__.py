@@ -33,6 +33,19 @@ from .kdtree import kdtree_construction, kdtree_knn_search, kdtree_radius_search
 from .octree import octree_construction, octree_knn_search, octree_radius_search, octree_radius_search_fast  # noqa: F401
 from .iss import iss_keypoints  # noqa: F401
 from .pca_normal import PCA, estimate_normals  # noqa: F401
+from .global_registration import (  # noqa: F401
+    Feature,
+    RegistrationResult,
+    compute_fpfh_feature,
+    estimate_normals_hybrid,
+    execute_global_registration,
+    find_matchings,
+    prepare_dataset,
+    preprocess_point_cloud,
+    ransac_init,
+    registration_ransac_based_on_feature_matching,
+    voxel_down_sample,
+)
 from .batch import register_batch, shard_range  # noqa: F401
 from . import evaluate  # noqa: F401
 from .evaluate import evaluate_rt, get_P_diff, is_registration_successful  # noqa: F401

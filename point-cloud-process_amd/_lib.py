@@ -47,6 +47,31 @@ class IcpParams(C.Structure):
     ]
 
 
+class RansacParams(C.Structure):
+    _fields_ = [
+        ("max_iteration", C.c_int32),
+        ("check_distance", C.c_int32),
+        ("confidence", C.c_double),
+        ("max_distance", C.c_double),
+        ("edge_similarity", C.c_double),
+        ("seed", C.c_uint64),
+        ("reserved", C.c_double * 4),
+    ]
+
+
+class RansacResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_double * 16),
+        ("iterations", C.c_int32),
+        ("n_valid", C.c_int32),
+        ("best_iteration", C.c_int32),
+        ("reserved_i", C.c_int32),
+        ("corr_fitness", C.c_double),
+        ("corr_rmse", C.c_double),
+        ("reserved", C.c_double * 4),
+    ]
+
+
 class IcpResult(C.Structure):
     _fields_ = [
         ("T", C.c_double * 16),
@@ -106,6 +131,11 @@ SIGNATURES = {
     "pcr_iss": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _ip, _ip, C.POINTER(C.c_int)]),
     "pcr_pca": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
     "pcr_normals": (C.c_int, [_vp, _vp, C.c_int, _dp, _dp, _ip]),
+    "pcr_normals_hybrid": (C.c_int, [_vp, _vp, C.c_double, C.c_int, C.c_int, _dp, _dp]),
+    "pcr_fpfh": (C.c_int, [_vp, _vp, _dp, C.c_double, C.c_int, _dp]),
+    "pcr_feature_match": (C.c_int, [_vp, _dp, C.c_int64, _dp, C.c_int64, C.c_int, _ip, _dp]),
+    "pcr_ransac_default_params": (C.c_int, [C.POINTER(RansacParams)]),
+    "pcr_ransac": (C.c_int, [_vp, _vp, _vp, _ip, C.c_int64, C.POINTER(RansacParams), C.POINTER(RansacResult)]),
     "pcr_debug_read": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int64]),
     "pcr_profile_enable": (C.c_int, [_vp, C.c_int]),
     "pcr_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),

@@ -294,6 +294,19 @@ static int upload_impl(pcr_ctx* ctx, const S* xyz, int64_t n, int64_t stride, pc
     return PCR_OK;
 }
 
+__global__ void cloud_rows_kernel(const pcr_pt* __restrict__ in, long long n, pcr_pt* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const pcr_pt p = in[i];
+    out[p.id] = p;
+}
+
+int pcr_cloud_rows(pcr_ctx* ctx, const pcr_cloud* c, pcr_pt* d_out) {
+    hipLaunchKernelGGL(cloud_rows_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)c->d, (long long)c->n, d_out);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
 extern "C" {
 
 int pcr_cloud_upload_f32(pcr_ctx* ctx, const float* xyz, int64_t n, int64_t stride, pcr_cloud** out) {

@@ -106,6 +106,8 @@ struct pcr_ctx {
 
 PCR_HIDDEN int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out);
 PCR_HIDDEN void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes);
+// records of a cloud in caller row order (the device copy may be Morton-reordered)
+PCR_HIDDEN int pcr_cloud_rows(pcr_ctx* ctx, const pcr_cloud* c, pcr_pt* d_out);
 PCR_HIDDEN int pcr_ensure_scratch(pcr_ctx* ctx, size_t partial_bytes);
 PCR_HIDDEN void pcr_xform_from_T(const double* T, pcr_xform* x);
 // profile helpers: mark slot boundary k (0..4) on the stream; finish() syncs and accumulates

@@ -1,15 +1,16 @@
-// Host-side 3x3 linear algebra for the Procrustes step (binary64).
+// 3x3 linear algebra for the Procrustes step (binary64), usable from host code and from kernels.
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <hip/hip_runtime.h>
 
 namespace pcr {
 
 // One-sided Jacobi SVD of a 3x3 matrix (row-major): H = U diag(s) V^T.
 // Columns of U for zero singular values are completed to an orthonormal basis.
-inline void svd3(const double H[9], double U[9], double s[3], double V[9]) {
+__host__ __device__ inline void svd3(const double H[9], double U[9], double s[3], double V[9]) {
     double A[9];
-    std::memcpy(A, H, sizeof(A));
+    for (int i = 0; i < 9; ++i) A[i] = H[i];
     for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0.0;
@@ -22,12 +23,12 @@ inline void svd3(const double H[9], double U[9], double s[3], double V[9]) {
                     gamma += A[3 * i + p] * A[3 * i + q];
                 }
                 if (gamma == 0.0) continue;
-                double lim = 1e-17 * std::sqrt(alpha * beta);
-                if (std::fabs(gamma) <= lim) continue;
-                off = std::fmax(off, std::fabs(gamma) / std::sqrt(alpha * beta));
+                double lim = 1e-17 * sqrt(alpha * beta);
+                if (fabs(gamma) <= lim) continue;
+                off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
                 double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
                 for (int i = 0; i < 3; ++i) {
                     double ap = A[3 * i + p], aq = A[3 * i + q];
                     A[3 * i + p] = c * ap - sn * aq;
@@ -43,8 +44,8 @@ inline void svd3(const double H[9], double U[9], double s[3], double V[9]) {
     double nrm[3];
     double nmax = 0;
     for (int j = 0; j < 3; ++j) {
-        nrm[j] = std::sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
-        nmax = std::fmax(nmax, nrm[j]);
+        nrm[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+        nmax = fmax(nmax, nrm[j]);
     }
     bool ok[3];
     for (int j = 0; j < 3; ++j) {
@@ -68,11 +69,11 @@ inline void svd3(const double H[9], double U[9], double s[3], double V[9]) {
         int g = -1;
         for (int j = 0; j < 3; ++j) if (ok[j]) g = j;
         if (g >= 0) { u0[0] = U[g]; u0[1] = U[3 + g]; u0[2] = U[6 + g]; }
-        int ax = (std::fabs(u0[0]) <= std::fabs(u0[1]) && std::fabs(u0[0]) <= std::fabs(u0[2])) ? 0 : (std::fabs(u0[1]) <= std::fabs(u0[2]) ? 1 : 2);
+        int ax = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
         double e[3] = {0, 0, 0};
         e[ax] = 1.0;
         double v1[3] = {u0[1] * e[2] - u0[2] * e[1], u0[2] * e[0] - u0[0] * e[2], u0[0] * e[1] - u0[1] * e[0]};
-        double n1 = std::sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
+        double n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
         for (int i = 0; i < 3; ++i) v1[i] /= n1;
         double v2[3] = {u0[1] * v1[2] - u0[2] * v1[1], u0[2] * v1[0] - u0[0] * v1[2], u0[0] * v1[1] - u0[1] * v1[0]};
         int cols[3], nc = 0;
@@ -85,7 +86,7 @@ inline void svd3(const double H[9], double U[9], double s[3], double V[9]) {
     }
 }
 
-inline void mat3_mul(const double A[9], const double B[9], double C[9]) {
+__host__ __device__ inline void mat3_mul(const double A[9], const double B[9], double C[9]) {
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
@@ -94,7 +95,7 @@ inline void mat3_mul(const double A[9], const double B[9], double C[9]) {
 //   m = {K, Sa[3], Sb[3], Sba[9] (b_i a_j), Saa, Sbb}
 // R = U V^T of H = sum (b-bbar)(a-abar)^T (no reflection fix, like Registration/main.py:137-139),
 // t = bbar - R abar, cost = ||B - (R A + t)||_F (main.py:140-141).
-inline void kabsch_from_moments(const double m[18], const double origin[3], double R[9], double t[3], double* cost) {
+__host__ __device__ inline void kabsch_from_moments(const double m[18], const double origin[3], double R[9], double t[3], double* cost) {
     const double K = m[0];
     double abar[3] = {m[1] / K, m[2] / K, m[3] / K};
     double bbar[3] = {m[4] / K, m[5] / K, m[6] / K};
@@ -115,7 +116,7 @@ inline void kabsch_from_moments(const double m[18], const double origin[3], doub
         double tr = 0;  // trace(R^T H) = sum_ij R_ij H_ij
         for (int i = 0; i < 9; ++i) tr += R[i] * H[i];
         double c2 = sbb + saa - 2.0 * tr;
-        *cost = c2 > 0 ? std::sqrt(c2) : 0.0;
+        *cost = c2 > 0 ? sqrt(c2) : 0.0;
     }
 }
 

@@ -139,17 +139,25 @@ __device__ static inline unsigned long long splitmix64(unsigned long long x) {
     return x ^ (x >> 31);
 }
 
-// one thread per emitted voxel v in [0, n_groups - 1): the last group is never emitted
+// one thread per emitted voxel v in [0, n_groups - 1): the last group is never emitted (modes 0, 1); mode 2 emits all
 __global__ void voxel_emit_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restrict__ perm, const unsigned int* __restrict__ heads,
                                   const unsigned int* __restrict__ n_groups_p, long long n, int mode, unsigned long long seed,
                                   pcr_pt* __restrict__ out_pts, double* __restrict__ out_xyz) {
     const unsigned int ng = *n_groups_p;
     const unsigned int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ng == 0 || v >= ng - 1) return;
-    const unsigned int s = heads[v], e = heads[v + 1];
+    if (ng == 0 || v >= (mode == 2 ? ng : ng - 1)) return;
+    const unsigned int s = heads[v], e = v + 1 < ng ? heads[v + 1] : (unsigned int)n;
     const unsigned int cnt = e - s;
     double ox, oy, oz;
-    if (mode == 0) {
+    if (mode == 2) {
+        // Open3D voxel_down_sample: running sum in input order, then one division
+        ox = oy = oz = 0.0;
+        for (unsigned int k = 0; k < cnt; ++k) {
+            const pcr_pt p = pts[perm[s + k]];
+            ox += p.x; oy += p.y; oz += p.z;
+        }
+        ox /= (double)cnt; oy /= (double)cnt; oz /= (double)cnt;
+    } else if (mode == 0) {
         coord_view a{pts, perm, s, 0};
         ox = numpy_pairwise_sum(a, cnt) / (double)cnt;
         a.axis = 1;
@@ -183,12 +191,21 @@ struct voxel_work {
 };
 
 // keys + sort + heads on a device cloud.  h_out_dev (by row id) optional.
-static int voxel_prepare(pcr_ctx* ctx, const pcr_cloud* c, double leaf, double* h_out_dev, bool need_groups, voxel_work* w) {
+static int voxel_prepare(pcr_ctx* ctx, const pcr_cloud* c, double leaf, double* h_out_dev, bool need_groups, voxel_work* w,
+                         bool open3d_binning = false) {
     if (!(leaf > 0) || !std::isfinite(leaf)) return PCR_E_INVALID;
     const long long n = c->n;
     w->n = n;
     int rc = pcr_bbox(ctx, c->d, n, w->mn, w->mx);
     if (rc) return rc;
+    if (open3d_binning) {
+        // Open3D: voxel_min_bound = min - voxel_size/2, index = floor((p - voxel_min_bound) / voxel_size); every cell distinct
+        for (int k = 0; k < 3; ++k) {
+            w->mn[k] -= leaf * 0.5;
+            w->D[k] = floor((w->mx[k] - w->mn[k]) / leaf) + 1.0;
+        }
+        if (w->D[0] * w->D[1] * w->D[2] >= 9007199254740992.0) { ctx->last_error = "voxel_size is too small"; return PCR_E_INVALID; }
+    } else
     for (int k = 0; k < 3; ++k) w->D[k] = npy_floor_divide(w->mx[k] - w->mn[k], leaf);
     const int block = 256;
     const int grid_n = (int)((n + block - 1) / block);
@@ -264,14 +281,14 @@ int pcr_voxel_keys(pcr_ctx* ctx, const double* xyz, int64_t n, double leaf, doub
 
 static int voxel_filter_impl(pcr_ctx* ctx, const pcr_cloud* in, double leaf, int mode, uint64_t seed, pcr_pt* out_pts, double* out_xyz_dev,
                              int64_t* n_out) {
-    if (mode != 0 && mode != 1) return PCR_E_INVALID;
+    if (mode != 0 && mode != 1 && mode != 2) return PCR_E_INVALID;
     voxel_work w;
-    int rc = voxel_prepare(ctx, in, leaf, nullptr, true, &w);
+    int rc = voxel_prepare(ctx, in, leaf, nullptr, true, &w, mode == 2);
     if (rc) { voxel_release(ctx, &w); return rc; }
     unsigned int ng = 0;
     PCR_HIP(ctx, hipMemcpyAsync(&ng, w.n_groups, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t rows = ng > 0 ? (int64_t)ng - 1 : 0;
+    const int64_t rows = mode == 2 ? (int64_t)ng : (ng > 0 ? (int64_t)ng - 1 : 0);
     if (rows > 0) {
         const int block = 128;
         hipLaunchKernelGGL(voxel_emit_kernel, dim3((unsigned)((rows + block - 1) / block)), dim3(block), 0, ctx->stream,

@@ -127,9 +127,18 @@ def ICP(src_cloud, tgt_cloud, *, init=None, max_iteration=50, R_diff_thres=1e-5,
     (icp_template.py:157-159,115); the defaults here are tight thresholds so the
     loop actually converges, R_diff is the geodesic angle the template links to
     (icp_template.py:184).  ``init`` replaces ``ransac_init`` (icp_template.py:145-152):
-    a 4x4 initial guess applied to the source and folded into ``homo_mat_total``.
+    a 4x4 initial guess applied to the source and folded into ``homo_mat_total``; ``init="ransac"`` runs
+    ``ransac_init`` itself like the template's ``init_use_ransac = True``.
     """
     ctx = ctx or default_context()
+    if isinstance(init, str):
+        if init != "ransac":
+            raise ValueError("init must be a 4x4 transform, None or 'ransac'")
+        from .global_registration import ransac_init
+
+        R_init, t_init = ransac_init(src_cloud, tgt_cloud, ctx=ctx)
+        init = np.eye(4)
+        init[:3, :3], init[:3, 3] = R_init, t_init[:, 0]
     T0 = np.eye(4) if init is None else np.array(init, dtype=np.float64).reshape(4, 4)
     src_dev = DeviceCloud.upload(points_of(src_cloud), ctx)
     if isinstance(tgt_cloud, (TargetIndex, KDTreeFlann)):
