@@ -100,6 +100,44 @@ def run_icp_steps(pkg, index, src_host, steps, ctx):
     return out
 
 
+def concurrent_leg(pkg, dev_id, src, tgt, n_pairs, steps):
+    """Aggregate throughput with `n_pairs` independent copies of the workload in flight on ONE GPU (one context =
+    one HIP stream per pair, one host thread each): what a rank of the batched job (BASELINE configs[3]) does.  A single
+    pair is latency-bound (three dependent launches per iteration); this leg shows the throughput bound."""
+    import threading
+
+    ctxs = [pkg.Context(dev_id) for _ in range(n_pairs)]
+    work = []
+    for c in ctxs:
+        idx = pkg.TargetIndex(pkg.DeviceCloud.upload(tgt, c), ctx=c)
+        work.append((pkg.DeviceCloud.upload(src, c).prepare(idx), idx))
+
+    def run(i, k):
+        sd, idx = work[i]
+        pkg.icp_device(sd, idx, np.eye(4), mode="total", max_iter=k, r_thres=-1.0, t_thres=-1.0, max_d2=MAX_D2, min_iter=k)
+
+    def wave(k):
+        th = [threading.Thread(target=run, args=(i, k)) for i in range(n_pairs)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for c in ctxs:
+            c.sync()
+
+    wave(5)
+    t0 = time.perf_counter()
+    wave(steps)
+    el = time.perf_counter() - t0
+    for sd, idx in work:
+        sd.free()
+        idx.free()
+    for c in ctxs:
+        c.close()
+    return {"pairs_in_flight": n_pairs, "steps_per_pair": steps, "value": float(len(src)) * steps * n_pairs / el,
+            "unit": "correspondences/s", "ms_per_icp_iter_per_pair": 1e3 * el / steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +150,7 @@ def main():
     ap.add_argument("--cell", type=float, default=0.0, help="level-0 cell size of the grid index in metres (0 = automatic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-brute", action="store_true", help="skip the brute-force MFMA leg")
+    ap.add_argument("--in-flight", type=int, default=4, help="pairs in flight for the supplementary concurrent leg (0 = skip)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -246,6 +285,8 @@ def main():
                              "dtype": "f64 (v_mfma_f64_16x16x4_f64)"},
             }
             ib.free()
+        if world == 1 and a.nn == "grid" and a.in_flight > 1:
+            line["concurrent_pairs"] = concurrent_leg(pkg, dev_id, src, tgt, a.in_flight, min(a.steps, 100))
         if world == 1 and not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(src, tgt)
         print(json.dumps(line))

@@ -50,6 +50,7 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
     hipEventCreate(&c->ev3);
     c->h_pinned_bytes = 4096;
     c->zero_copy = getenv("PCR_NO_ZEROCOPY") == nullptr;
+    if (const char* l = getenv("PCR_ICP_LANES")) c->icp_lanes = atoi(l) < 1 ? 1 : atoi(l);
     if (hipHostMalloc((void**)&c->h_pinned, c->h_pinned_bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         delete c;
         return PCR_E_NOMEM;
@@ -78,6 +79,8 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     hipEventDestroy(c->ev3);
     for (int i = 0; i < 5; ++i)
         if (c->pev[i]) hipEventDestroy(c->pev[i]);
+    for (int l = 0; l < PCR_MAX_LANES; ++l)
+        if (c->lane_stream[l]) hipStreamDestroy(c->lane_stream[l]);
     hipStreamDestroy(c->stream);
     delete c;
     return PCR_OK;
@@ -199,6 +202,12 @@ void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes) {
     bytes = (bytes + 255) & ~size_t(255);
     // frees are stream-ordered with later allocations because every user of the block runs on ctx->stream
     ctx->free_list.push_back({p, bytes});
+}
+
+int pcr_ctx_lanes(pcr_ctx* ctx, int lanes) {
+    for (int l = 0; l < lanes && l < PCR_MAX_LANES; ++l)
+        if (!ctx->lane_stream[l]) PCR_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking));
+    return PCR_OK;
 }
 
 int pcr_ensure_scratch(pcr_ctx* ctx, size_t partial_bytes) {

@@ -23,6 +23,7 @@
 // final answer, so every stage returns the exact nearest neighbour (lowest index on ties).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include "pcr_grid_dev.h"
 
 constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
@@ -92,18 +93,14 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
     const bool qvalid = qi < nq;
     // ---- load + transform the tile's queries (wave 0 writes back)
     double ax = 0, ay = 0, az = 0;
+    long long qid = 0;
     bool clamped = false;
     int cx = 0, cy = 0, cz = 0;
     if (qvalid) {
         pcr_pt p = q[qi];
         ax = p.x; ay = p.y; az = p.z;
-        if (has_x) {
-            xform_apply(x, p, &ax, &ay, &az);
-            if (write_back && wave == 0) {
-                p.x = ax; p.y = ay; p.z = az;
-                q[qi] = p;
-            }
-        }
+        qid = p.id;
+        if (has_x) xform_apply(x, p, &ax, &ay, &az);
         cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
         cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
         cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
@@ -140,6 +137,13 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         }
     }
     __syncthreads();
+    // in-place transform of the source (main.py:110): wave 0 stores, and only after the barrier -- every wave of the
+    // block has loaded the untransformed record by now (a store before it raced with the other waves' loads)
+    if (has_x && write_back && wave == 0 && qvalid) {
+        pcr_pt p;
+        p.x = ax; p.y = ay; p.z = az; p.id = qid;
+        q[qi] = p;
+    }
     PH_STAMP(0);
     const int level = sm.level;
     double bd2 = DBL_MAX;
@@ -747,30 +751,28 @@ struct grid_scratch {
     int64_t nq = 0;
 };
 
-// Runs the search stages; leaves res_pos (and res_d2 when asked) on the device.
-static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xform* x, int write_back, double max_d2,
-                              bool gated, bool want_d2, grid_scratch* sc) {
+// Runs the search stages on `stream` over the `nq` records at `q` (a whole Morton-sorted cloud or a run of it);
+// leaves res_pos (and res_d2 when asked) on the device.
+static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, hipStream_t stream, unsigned int* hard_count,
+                              const pcr_xform* x, int write_back, double max_d2, bool gated, bool want_d2, bool mark, grid_scratch* sc) {
     int rc;
-    // tiles are runs of the Morton-sorted query cloud (sorted once; rigid motion keeps them compact)
-    if ((rc = pcr_cloud_morton_sort(ctx, qc, idx->cell))) return rc;
-    const int64_t nq = qc->n;
-    pcr_pt* q = qc->d;
     sc->nq = nq;
     const int nblocks = (int)((nq + TQ - 1) / TQ);
     if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * nq, (void**)&sc->res_pos))) return rc;
     if (want_d2 && (rc = pcr_dev_alloc(ctx, sizeof(double) * nq, (void**)&sc->res_d2))) return rc;
     if ((rc = pcr_dev_alloc(ctx, sizeof(work_item) * (size_t)nq, (void**)&sc->hard_list))) return rc;
-    sc->hard_count = ctx->d_counters + 96;  // zero at context creation, reset by the epilogue kernels
+    sc->hard_count = hard_count;  // zero at context creation, reset by the epilogue kernels
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
-    pcr_prof_mark(ctx, 0);
-    hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
+    if (mark) pcr_prof_mark(ctx, 0);
+    static const int dyn_lds = getenv("PCR_TILE_DYNLDS") ? atoi(getenv("PCR_TILE_DYNLDS")) : 0;  // experiment: caps blocks/CU
+    hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), dyn_lds, stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
                        write_back, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
-    pcr_prof_mark(ctx, 1);
+    if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;
     const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
-    hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, ctx->stream, idx->view, (const work_item*)sc->hard_list,
+    hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, stream, idx->view, (const work_item*)sc->hard_list,
                        (const unsigned int*)sc->hard_count, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
@@ -785,9 +787,12 @@ static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
 int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xform* x, double max_d2, int32_t* d_idx, double* d_d2) {
     const bool gated = (max_d2 > 0) && std::isfinite(max_d2);
     grid_scratch sc;
-    int rc = grid_search_launch(ctx, idx, qc, x, 0, max_d2, gated, true, &sc);
+    // tiles are runs of the Morton-sorted query cloud (sorted once; rigid motion keeps them compact)
+    int rc = pcr_cloud_morton_sort(ctx, qc, idx->cell);
     if (rc) return rc;
     const int64_t nq = qc->n;
+    rc = grid_search_launch(ctx, idx, qc->d, nq, ctx->stream, ctx->d_counters + 96, x, 0, max_d2, gated, true, true, &sc);
+    if (rc) return rc;
     const int grid = (int)((nq + 255) / 256);
     hipLaunchKernelGGL(grid_finalize_nn1_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq,
                        (const unsigned int*)sc.res_pos, (const double*)sc.res_d2, max_d2, gated ? 1 : 0, d_idx, d_d2, sc.hard_count);
@@ -799,22 +804,72 @@ int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xf
 int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xform* x, double max_d2, int write_back,
                       double* d_moments) {
     const bool gated = (max_d2 > 0) && std::isfinite(max_d2);
-    grid_scratch sc;
-    int rc = grid_search_launch(ctx, idx, qc, x, write_back, max_d2, gated, false, &sc);
+    const bool was_sorted = qc->morton_sorted;
+    int rc = pcr_cloud_morton_sort(ctx, qc, idx->cell);
     if (rc) return rc;
     const int64_t nq = qc->n;
-    int grid = (int)((nq + 1023) / 1024);  // four queries per thread
-    if (grid > ctx->cu_count) grid = ctx->cu_count;
-    if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid))) return rc;
-    // after a write-back pass the cloud already holds the transformed points
-    pcr_prof_mark(ctx, 2);
-    hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, *x,
-                       write_back ? 0 : 1, (const unsigned int*)sc.res_pos, max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
-                       d_moments, sc.hard_count);
-    pcr_prof_mark(ctx, 3);
-    pcr_prof_mark(ctx, 4);
-    PCR_HIP(ctx, hipGetLastError());
-    pcr_prof_finish(ctx);
-    grid_scratch_free(ctx, &sc);
+    // Lanes: the pass over one pair is a chain of three dependent launches and is latency-bound; runs of the sorted
+    // source are independent, so they go down separate streams and overlap each other's stalls.  Every lane reduces its
+    // own moments (fixed order); the host adds the lanes in lane order.  One lane while profiling (per-kernel events).
+    int lanes = ctx->profile ? 1 : ctx->icp_lanes;
+    if (lanes > PCR_MAX_LANES) lanes = PCR_MAX_LANES;
+    while (lanes > 1 && nq < (int64_t)lanes * 8192) --lanes;
+    if (lanes <= 1) {
+        grid_scratch sc;
+        rc = grid_search_launch(ctx, idx, qc->d, nq, ctx->stream, ctx->d_counters + 96, x, write_back, max_d2, gated, false, true, &sc);
+        if (rc) return rc;
+        int grid = (int)((nq + 1023) / 1024);  // four queries per thread
+        if (grid > ctx->cu_count) grid = ctx->cu_count;
+        if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid))) return rc;
+        // after a write-back pass the cloud already holds the transformed points
+        pcr_prof_mark(ctx, 2);
+        hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, *x,
+                           write_back ? 0 : 1, (const unsigned int*)sc.res_pos, max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
+                           d_moments, sc.hard_count);
+        pcr_prof_mark(ctx, 3);
+        pcr_prof_mark(ctx, 4);
+        PCR_HIP(ctx, hipGetLastError());
+        pcr_prof_finish(ctx);
+        grid_scratch_free(ctx, &sc);
+        return PCR_OK;
+    }
+    if ((rc = pcr_ctx_lanes(ctx, lanes))) return rc;
+    if (!was_sorted) PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sort ran on the main stream
+    if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)ctx->cu_count * lanes))) return rc;
+    grid_scratch sc[PCR_MAX_LANES];
+    const int64_t per = ((nq + lanes - 1) / lanes + 1023) / 1024 * 1024;
+    int used = 0;
+    for (int l = 0; l < lanes && rc == PCR_OK; ++l) {
+        const int64_t q0 = per * l, q1 = q0 + per < nq ? q0 + per : nq;
+        if (q0 >= q1) break;
+        ++used;
+        hipStream_t st = ctx->lane_stream[l];
+        rc = grid_search_launch(ctx, idx, qc->d + q0, q1 - q0, st, ctx->d_counters + 96 + 4 * l, x, write_back, max_d2, gated, false, false, &sc[l]);
+        if (rc) break;
+        int grid = (int)((q1 - q0 + 1023) / 1024);
+        if (grid > ctx->cu_count) grid = ctx->cu_count;
+        hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, st, idx->view, (const pcr_pt*)(qc->d + q0), (long long)(q1 - q0), *x,
+                           write_back ? 0 : 1, (const unsigned int*)sc[l].res_pos, max_d2, gated ? 1 : 0,
+                           ctx->d_partials + (size_t)PCR_NMOM * ctx->cu_count * l, ctx->d_counters + 64 + 8 * l, ctx->h_pinned + 32 * (l + 1),
+                           sc[l].hard_count);
+    }
+    hipError_t e = hipGetLastError();
+    for (int l = 0; l < used; ++l) {
+        const hipError_t es = hipStreamSynchronize(ctx->lane_stream[l]);
+        if (e == hipSuccess) e = es;
+        grid_scratch_free(ctx, &sc[l]);
+    }
+    if (rc) return rc;
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
+    double m[PCR_NMOM];
+    for (int k = 0; k < PCR_NMOM; ++k) {
+        double v = 0.0;
+        for (int l = 0; l < used; ++l) v += ctx->h_pinned[32 * (l + 1) + k];
+        m[k] = v;
+    }
+    // hand the sum over the way the single-lane pass does (the caller reads h_pinned, or copies d_moments)
+    if (d_moments == ctx->h_pinned) memcpy(ctx->h_pinned, m, sizeof(m));
+    else PCR_HIP(ctx, hipMemcpyAsync(d_moments, m, sizeof(m), hipMemcpyHostToDevice, ctx->stream));
+    if (d_moments != ctx->h_pinned) PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCR_OK;
 }

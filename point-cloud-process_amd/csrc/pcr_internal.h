@@ -79,6 +79,8 @@ struct pcr_ctx {
     // pinned host scratch for the per-iteration moment read-back
     double* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
+    int icp_lanes = 1;                    // runs of the source searched on separate streams per ICP pass (PCR_ICP_LANES)
+    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     bool zero_copy = true;  // kernels write small results straight into h_pinned (PCR_NO_ZEROCOPY=1 disables)
     // device scratch for per-block partial moments
     double* d_partials = nullptr;
@@ -108,6 +110,8 @@ PCR_HIDDEN int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out);
 PCR_HIDDEN void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes);
 // records of a cloud in caller row order (the device copy may be Morton-reordered)
 PCR_HIDDEN int pcr_cloud_rows(pcr_ctx* ctx, const pcr_cloud* c, pcr_pt* d_out);
+constexpr int PCR_MAX_LANES = 4;
+PCR_HIDDEN int pcr_ctx_lanes(pcr_ctx* ctx, int lanes);  // creates the lane streams on first use
 PCR_HIDDEN int pcr_ensure_scratch(pcr_ctx* ctx, size_t partial_bytes);
 PCR_HIDDEN void pcr_xform_from_T(const double* T, pcr_xform* x);
 // profile helpers: mark slot boundary k (0..4) on the stream; finish() syncs and accumulates

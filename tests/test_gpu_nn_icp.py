@@ -195,3 +195,19 @@ def test_nn1_dense_volume_and_clustered_duplicates(pcp, oracle):
     bi, bd2 = oracle.nn1_bruteforce(q, tgt)
     assert np.array_equal(d2, bd2)
     assert np.array_equal(idx, bi)  # np.argmin also returns the first (lowest) index on ties
+
+
+def test_icp_is_bitwise_reproducible(pcp, syn):
+    """Same inputs -> the same bits, run after run (fixed-order reductions, no order-dependent atomics, no races)."""
+    src, tgt, _ = syn.perturbed_pair(120000, seed=0)
+    index = pcp.TargetIndex(tgt)
+    outs = []
+    for rep in range(4):
+        sd = pcp.DeviceCloud.upload(src)
+        r = pcp.icp_device(sd, index, np.eye(4), mode="total", max_iter=30, r_thres=-1.0, t_thres=-1.0, min_iter=30)
+        outs.append((r["T_total"].tobytes(), r["n_assoc"], sd.download().tobytes()))
+        sd.free()
+    assert all(o == outs[0] for o in outs[1:])
+    idx0 = index.nn1(src)
+    idx1 = index.nn1(src)
+    assert np.array_equal(idx0[0], idx1[0]) and np.array_equal(idx0[1], idx1[1])
