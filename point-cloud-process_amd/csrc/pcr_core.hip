@@ -55,8 +55,8 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
         delete c;
         return PCR_E_NOMEM;
     }
-    if (hipMalloc((void**)&c->d_counters, 4096) != hipSuccess) { delete c; return PCR_E_NOMEM; }
-    hipMemsetAsync(c->d_counters, 0, 4096, c->stream);
+    if (hipMalloc((void**)&c->d_counters, PCR_COUNTER_BYTES) != hipSuccess) { delete c; return PCR_E_NOMEM; }
+    hipMemsetAsync(c->d_counters, 0, PCR_COUNTER_BYTES, c->stream);
     if (getenv("PCR_DEBUG_STAMPS")) {
         hipMalloc((void**)&c->d_debug, sizeof(unsigned long long) << 20);
         hipMemsetAsync(c->d_debug, 0, sizeof(unsigned long long) << 20, c->stream);

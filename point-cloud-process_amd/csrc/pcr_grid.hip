@@ -121,6 +121,47 @@ __global__ void insert_cells_kernel(const unsigned long long* __restrict__ keys,
     }
 }
 
+struct pcr_btables {
+    pcr_block_slot* t[PCR_MAX_LEVELS];
+    unsigned int mask[PCR_MAX_LEVELS];
+    unsigned int cap[PCR_MAX_LEVELS];
+};
+
+__global__ void init_blocks_kernel(pcr_btables bt, int levels) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int l = 0; l < levels; ++l)
+        if (i < bt.cap[l]) {
+            pcr_block_slot e;
+            e.key = PCR_EMPTY_KEY; e.start = 0xffffffffu; e.flags = 0;
+            for (int k = 0; k < 8; ++k) e.cnt[k] = 0;
+            bt.t[l][i] = e;
+        }
+}
+
+// one thread per slot of the cell tables: the cell registers itself in its 2x2x2 block
+__global__ void insert_blocks_kernel(pcr_tables tabs, pcr_btables bt, int levels) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int l = 0; l < levels; ++l) {
+        if (i >= (tabs.mask[l] + 1) * 4) continue;
+        const pcr_cell_slot c = tabs.t[l][i];
+        if (c.key == PCR_EMPTY_KEY) continue;
+        const unsigned int X = (unsigned int)(c.key & 0x1fffffull), Y = (unsigned int)((c.key >> 21) & 0x1fffffull), Z = (unsigned int)((c.key >> 42) & 0x1fffffull);
+        const unsigned int BX = X >> 1, BY = Y >> 1, BZ = Z >> 1;
+        const int child = (int)((X & 1) | ((Y & 1) << 1) | ((Z & 1) << 2));
+        const unsigned long long bk = cell_pack(BX, BY, BZ);
+        unsigned int b = cell_hash(BX, BY, BZ) & bt.mask[l];
+        for (unsigned int probe = 0; probe <= bt.mask[l]; ++probe) {
+            const unsigned long long old = atomicCAS(&bt.t[l][b].key, PCR_EMPTY_KEY, bk);
+            if (old == PCR_EMPTY_KEY || old == bk) break;
+            b = (b + 1) & bt.mask[l];
+        }
+        const unsigned int cnt = c.end - c.start;
+        if (cnt >= 0xffffu) atomicOr(&bt.t[l][b].flags, 1u);
+        bt.t[l][b].cnt[child] = (unsigned short)(cnt >= 0xffffu ? 0xffffu : cnt);
+        atomicMin(&bt.t[l][b].start, c.start);
+    }
+}
+
 // ------------------------------------------------------------------- host
 static int next_pow2(unsigned int v) {
     unsigned int p = 1;
@@ -217,6 +258,24 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
     }
     hipLaunchKernelGGL(insert_cells_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const unsigned long long*)d_keys2, n, levels, tabs);
     PCR_HIP(ctx, hipGetLastError());
+    // ---- 2x2x2-block tables (one line per 8 cells for the tile stage's directory)
+    pcr_btables bt;
+    memset(&bt, 0, sizeof(bt));
+    unsigned int max_cap = 16, max_bcap = 16;
+    for (int l = 0; l < levels; ++l) {
+        unsigned int bcap = (unsigned int)next_pow2(h_counts[l] * 2 + 4);  // blocks <= cells: load factor <= 0.5, usually ~0.15
+        if (bcap < 16) bcap = 16;
+        idx->bcaps[l] = bcap;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_block_slot) * bcap, (void**)&idx->btables[l]))) return rc;
+        bt.t[l] = idx->btables[l];
+        bt.mask[l] = bcap - 1;
+        bt.cap[l] = bcap;
+        if (bcap > max_bcap) max_bcap = bcap;
+        if (idx->caps[l] > max_cap) max_cap = idx->caps[l];
+    }
+    hipLaunchKernelGGL(init_blocks_kernel, dim3((max_bcap + 255) / 256), dim3(256), 0, ctx->stream, bt, levels);
+    hipLaunchKernelGGL(insert_blocks_kernel, dim3((max_cap + 255) / 256), dim3(256), 0, ctx->stream, tabs, bt, levels);
+    PCR_HIP(ctx, hipGetLastError());
     pcr_dev_free(ctx, d_temp, temp_bytes);
     pcr_dev_free(ctx, d_keys, sizeof(unsigned long long) * n);
     pcr_dev_free(ctx, d_keys2, sizeof(unsigned long long) * n);
@@ -237,6 +296,8 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
     for (int l = 0; l < levels; ++l) {
         v.table[l] = idx->tables[l];
         v.mask[l] = idx->caps[l] / 4 - 1;  // buckets of 4 slots
+        v.btable[l] = idx->btables[l];
+        v.bmask[l] = idx->bcaps[l] - 1;
     }
     return PCR_OK;
 }
@@ -287,6 +348,8 @@ void pcr_grid_free(pcr_ctx* ctx, pcr_index* idx) {
     for (int l = 0; l < PCR_MAX_LEVELS; ++l) {
         if (idx->tables[l]) pcr_dev_free(ctx, idx->tables[l], sizeof(pcr_cell_slot) * idx->caps[l]);
         idx->tables[l] = nullptr;
+        if (idx->btables[l]) pcr_dev_free(ctx, idx->btables[l], sizeof(pcr_block_slot) * idx->bcaps[l]);
+        idx->btables[l] = nullptr;
     }
 }
 

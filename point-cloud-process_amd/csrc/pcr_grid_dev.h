@@ -83,6 +83,20 @@ __device__ static inline bool lookup_cell(const pcr_cell_slot* __restrict__ tab,
     return false;
 }
 
+// 2x2x2-block lookup: one 32-byte read in almost every case
+__device__ static inline bool lookup_block(const pcr_block_slot* __restrict__ tab, unsigned int mask, unsigned int bx, unsigned int by,
+                                           unsigned int bz, pcr_block_slot* out) {
+    const unsigned long long key = cell_pack(bx, by, bz);
+    unsigned int b = cell_hash(bx, by, bz) & mask;
+    for (unsigned int probe = 0; probe <= mask; ++probe) {
+        const pcr_block_slot e = tab[b];
+        if (e.key == key) { *out = e; return true; }
+        if (e.key == PCR_EMPTY_KEY) return false;
+        b = (b + 1) & mask;
+    }
+    return false;
+}
+
 __device__ static inline bool better(double d2, long long id, double bd2, long long bid) {
     return d2 < bd2 || (d2 == bd2 && id < bid);
 }

@@ -28,12 +28,20 @@
 
 constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
 constexpr int T_MAXC = 1024;                // cells in a tile box
-constexpr int T_CPT = T_MAXC / 256;         // cells looked up per thread
 constexpr int T_PMAX = 512;                 // points staged per round
 constexpr unsigned int T_PCAP = 4 * T_PMAX;   // tiles with more candidate points than this go per-query
 constexpr unsigned int HARD_SCAN_T = 192;   // the hard stage scans cells up to this size, descends into bigger ones
 constexpr int HARD_STACK = 160;
 constexpr long long ID_NONE = 0x7fffffffffffffffll;
+// The unresolved queries go to H_NLIST sub-lists (tile t appends to list t % H_NLIST): one returning atomic per tile on
+// a single counter serialises at ~88/us on this chip -- 21 us for the 1875 tiles of a 120k scan, all finishing together.
+// Counter j lives at hard_count[H_CSTRIDE * j] (separate cache lines); list j is hard_list[j * cap, (j + 1) * cap).
+constexpr int H_NLIST = 32;
+constexpr int H_CSTRIDE = 32;
+__host__ __device__ static inline unsigned int hard_list_cap(long long nq) {
+    const long long tiles = (nq + 63) / 64;
+    return (unsigned int)(((tiles + H_NLIST - 1) / H_NLIST) * 64);
+}
 
 template <int G>
 __device__ static inline void group_best(double& bd2, long long& bid, unsigned int& bpos) {
@@ -61,6 +69,12 @@ __device__ static inline double vmin(double a, double b) {  // plain v_min_f64 (
     return r;
 }
 
+__device__ static inline float fmin3(float a, float b, float c) {  // v_min3_f32 (inputs are never NaN here)
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ static inline double sq_pos(double v) {
     v = fmax(v, 0.0);
     return v * v;
@@ -68,7 +82,7 @@ __device__ static inline double sq_pos(double v) {
 
 // -------------------------------------------------------------------- tile
 struct tile_smem {
-    float px[T_PMAX + 8], py[T_PMAX + 8], pz[T_PMAX + 8];  // staged candidates, binary32 about the tile centre (SoA, padded to 8)
+    alignas(16) float px[T_PMAX + 8], py[T_PMAX + 8], pz[T_PMAX + 8];  // staged candidates, binary32 about the tile centre (SoA, padded to 8)
     unsigned int ppos[T_PMAX];
     unsigned int c_start[T_MAXC];
     unsigned int c_off[T_MAXC + 1];  // exclusive prefix of the cell counts
@@ -153,55 +167,87 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
     if (level >= 0) {
         // ---- cell directory: every thread looks up cells of the box
         const int ncell = sm.ncell;
-        const int d0 = sm.dims[0], d1 = sm.dims[1];
+        const int d0 = sm.dims[0], d1 = sm.dims[1], d01 = d0 * d1;
         const int lim = (int)(PCR_COORD_MAX >> (2 * level));
-        // thread t looks up cells t, t+256, ... (independent 64-B bucket reads)
-        unsigned int my_cnt[T_CPT];
+        // Directory of the box's cells through the 2x2x2-block table: one 32-byte slot answers 8 cells (their runs are
+        // consecutive in the sorted cloud), so a tile reads ~ncell/5 random lines instead of ncell.  (The gather rounds
+        // of this kernel are bound by the misses a CU can keep in flight, not by bytes or address-coalescer cycles:
+        // four 16-byte loads per lane and one coalesced line per quad took the same 12 us.)
+        {
+            for (int c = tid; c < ncell; c += 256) { sm.c_start[c] = 0; sm.c_off[c] = 0; }
+            const int bx0 = sm.box_lo[0] >> 1, by0 = sm.box_lo[1] >> 1, bz0 = sm.box_lo[2] >> 1;
+            const int nb0 = ((sm.box_lo[0] + d0 - 1) >> 1) - bx0 + 1, nb1 = ((sm.box_lo[1] + d1 - 1) >> 1) - by0 + 1;
+            const int nb2 = ((sm.box_lo[2] + sm.dims[2] - 1) >> 1) - bz0 + 1;
+            const int nb01 = nb0 * nb1, nblk = nb01 * nb2;
+            const float binv0 = 1.0f / (float)nb0, binv01 = 1.0f / (float)nb01;
+            const int blim = lim >> 1;
+            __syncthreads();
+            for (int bq = tid; bq < nblk; bq += 256) {
+                int iz = (int)((float)bq * binv01);
+                iz -= (iz * nb01 > bq);
+                iz += ((iz + 1) * nb01 <= bq);
+                const int rem = bq - iz * nb01;
+                int iy = (int)((float)rem * binv0);
+                iy -= (iy * nb0 > rem);
+                iy += ((iy + 1) * nb0 <= rem);
+                const int ix = rem - iy * nb0;
+                const int BX = bx0 + ix, BY = by0 + iy, BZ = bz0 + iz;
+                if (BX < 0 || BY < 0 || BZ < 0 || BX > blim || BY > blim || BZ > blim) continue;
+                pcr_block_slot e;
+                if (!lookup_block(gv.btable[level], gv.bmask[level], (unsigned int)BX, (unsigned int)BY, (unsigned int)BZ, &e)) continue;
+                unsigned int run = e.start;
 #pragma unroll
-        for (int r = 0; r < T_CPT; ++r) {
-            const int c = tid + r * 256;
-            my_cnt[r] = 0;
-            if (c < ncell) {
-                const int ix = c % d0, iy = (c / d0) % d1, iz = c / (d0 * d1);
-                const int X = sm.box_lo[0] + ix, Y = sm.box_lo[1] + iy, Z = sm.box_lo[2] + iz;
-                unsigned int s = 0, e = 0;
-                if (X >= 0 && Y >= 0 && Z >= 0 && X <= lim && Y <= lim && Z <= lim)
-                    lookup_cell(gv.table[level], gv.mask[level], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &s, &e);
-                sm.c_start[c] = s;
-                my_cnt[r] = e - s;
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int X = 2 * BX + (ch & 1) - sm.box_lo[0], Y = 2 * BY + ((ch >> 1) & 1) - sm.box_lo[1], Z = 2 * BZ + (ch >> 2) - sm.box_lo[2];
+                    unsigned int cs = run, cn = e.cnt[ch];
+                    if (e.flags) {  // a child too large for 16 bits: ask the cell table
+                        unsigned int s2 = 0, e2 = 0;
+                        lookup_cell(gv.table[level], gv.mask[level], (unsigned int)(2 * BX + (ch & 1)), (unsigned int)(2 * BY + ((ch >> 1) & 1)),
+                                    (unsigned int)(2 * BZ + (ch >> 2)), &s2, &e2);
+                        cs = s2; cn = e2 - s2;
+                    }
+                    run += cn;
+                    if (X >= 0 && Y >= 0 && Z >= 0 && X < d0 && Y < d1 && Z < sm.dims[2]) {
+                        const int c = X + Y * d0 + Z * d01;
+                        sm.c_start[c] = cs;
+                        sm.c_off[c] = cn;
+                    }
+                }
             }
         }
+        __syncthreads();
         PH_STAMP(1);
-        // block exclusive scan in cell order (c = r*256 + tid): per-r wave scans + one barrier
+        // block exclusive scan of the cell counts held in c_off: thread t owns cells 4t .. 4t+3
         {
-            unsigned int inc[T_CPT];
+            unsigned int cnt4[4];
+            unsigned int mine = 0;
 #pragma unroll
-            for (int r = 0; r < T_CPT; ++r) inc[r] = my_cnt[r];
+            for (int u = 0; u < 4; ++u) {
+                const int c = tid * 4 + u;
+                cnt4[u] = c < ncell ? sm.c_off[c] : 0u;
+                mine += cnt4[u];
+            }
+            unsigned int inc = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-                for (int r = 0; r < T_CPT; ++r) {
-                    const unsigned int o = __shfl_up(inc[r], off, 64);
-                    if (lane >= off) inc[r] += o;
-                }
+                const unsigned int o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
             }
-            if (lane == 63) {
-#pragma unroll
-                for (int r = 0; r < T_CPT; ++r) sm.scan_tmp[r * 4 + wave] = inc[r];
-            }
+            if (lane == 63) sm.scan_tmp[wave] = inc;
             __syncthreads();
-            unsigned int run = 0;  // sum of all cells before (r, wave 0)
+            unsigned int base = 0, run = 0;
 #pragma unroll
-            for (int r = 0; r < T_CPT; ++r) {
-                unsigned int base = run;
+            for (int w = 0; w < 4; ++w) {
+                const unsigned int t = sm.scan_tmp[w];
+                if (w < wave) base += t;
+                run += t;
+            }
+            unsigned int pre = base + inc - mine;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned int t = sm.scan_tmp[r * 4 + w];
-                    if (w < wave) base += t;
-                    run += t;
-                }
-                const int c = tid + r * 256;
-                if (c < ncell) sm.c_off[c] = base + inc[r] - my_cnt[r];
+            for (int u = 0; u < 4; ++u) {
+                const int c = tid * 4 + u;
+                if (c < ncell) sm.c_off[c] = pre;
+                pre += cnt4[u];
             }
             if (tid == 0) { sm.c_off[ncell] = run; sm.total = run; }
             __syncthreads();
@@ -215,7 +261,8 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         // filter distance exceeds U the winner IS the exact nearest neighbour (its distance is then
         // recomputed in binary64, direct form).  Otherwise the query is ambiguous (near-tie or duplicate
         // targets) and goes to the exact hard stage.
-        float fm = INFINITY, fs = INFINITY;  // smallest / second smallest filter distance
+        float fm = INFINITY, fs = INFINITY;  // smallest / second smallest group minimum of the filter distances
+        float s_in = INFINITY;               // runner-up inside the winner's own group
         if (total <= T_PCAP) {
             staged = true;
             const double cellL = gv.cell0 * (double)(1ll << (2 * level));
@@ -248,35 +295,60 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
                 PH_STAMP(3);
                 if (tid < 8) { sm.px[cnt + tid] = 1e30f; sm.py[cnt + tid] = 0.0f; sm.pz[cnt + tid] = 0.0f; }  // padding of the last group of 8
                 __syncthreads();
-                // evaluation: wave w takes groups of 8 staged points; lane = query
+                // evaluation: wave w takes groups of 8 staged points; lane = query.  Per group: 12 packed ops for the 8
+                // distances, 4 v_min3/v_min for the group minimum, then ONE tracker update (smallest / second-smallest
+                // group minimum, and which group) -- 4 VALU ops per candidate instead of 7 with a per-candidate tracker.
+                // The winner's position inside its group and the group's own runner-up are recovered after the round.
                 int rk = -1;
                 for (unsigned int k0 = wave * 8; k0 < cnt; k0 += 32) {
+                    f2 d[4];
+                    typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const unsigned int k = k0 + 2 * u;
-                        const f2 bx = *reinterpret_cast<const f2*>(&sm.px[k]);
-                        const f2 by = *reinterpret_cast<const f2*>(&sm.py[k]);
-                        const f2 bz = *reinterpret_cast<const f2*>(&sm.pz[k]);
-                        const f2 dx = qx2 - bx, dy = qy2 - by, dz = qz2 - bz;
-                        f2 d = dx * dx;
-                        d = __builtin_elementwise_fma(dy, dy, d);
-                        d = __builtin_elementwise_fma(dz, dz, d);
+                    for (int u = 0; u < 2; ++u) {  // 16-byte LDS reads: 4 candidates per ds_read_b128
+                        const unsigned int k = k0 + 4 * u;
+                        const f4 bx4 = *reinterpret_cast<const f4*>(&sm.px[k]);
+                        const f4 by4 = *reinterpret_cast<const f4*>(&sm.py[k]);
+                        const f4 bz4 = *reinterpret_cast<const f4*>(&sm.pz[k]);
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const float dv = h ? d.y : d.x;
-                            const bool lt = dv < fm;
-                            fs = __builtin_amdgcn_fmed3f(dv, fm, fs);               // second smallest of {fm <= fs, dv}
-                            fm = __builtin_amdgcn_fmed3f(dv, fm, -INFINITY);         // min(dv, fm)
-                            rk = lt ? (int)(k + h) : rk;
+                            const f2 bx = h ? f2{bx4.z, bx4.w} : f2{bx4.x, bx4.y};
+                            const f2 by = h ? f2{by4.z, by4.w} : f2{by4.x, by4.y};
+                            const f2 bz = h ? f2{bz4.z, bz4.w} : f2{bz4.x, bz4.y};
+                            const f2 dx = qx2 - bx, dy = qy2 - by, dz = qz2 - bz;
+                            f2 t = dx * dx;
+                            t = __builtin_elementwise_fma(dy, dy, t);
+                            d[2 * u + h] = __builtin_elementwise_fma(dz, dz, t);
                         }
                     }
+                    float m8 = fmin3(d[0].x, d[0].y, d[1].x);
+                    m8 = fmin3(m8, d[1].y, d[2].x);
+                    m8 = fmin3(m8, d[2].y, d[3].x);
+                    m8 = fmin3(m8, d[3].y, d[3].y);
+                    const bool lt = m8 < fm;
+                    fs = __builtin_amdgcn_fmed3f(m8, fm, fs);           // second smallest of {fm <= fs, m8}
+                    fm = __builtin_amdgcn_fmed3f(m8, fm, -INFINITY);     // min(m8, fm)
+                    rk = lt ? (int)k0 : rk;
                 }
-                if (rk >= 0) bpos = sm.ppos[rk];
+                if (rk >= 0) {
+                    // this round produced the wave's current winner: locate it in its group; the group's runner-up joins
+                    // the second-smallest test (every other group is covered by fs)
+                    float best = INFINITY, second = INFINITY;
+                    int bi = rk;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float ddx = qxf - sm.px[rk + j], ddy = qyf - sm.py[rk + j], ddz = qzf - sm.pz[rk + j];
+                        const float dj = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx));
+                        if (dj < best) { second = best; best = dj; bi = rk + j; }
+                        else if (dj < second) second = dj;
+                    }
+                    bpos = sm.ppos[bi];
+                    s_in = second;
+                }
                 __syncthreads();
             }
         }
         sm.m_m[wave][lane] = fm;
-        sm.m_s[wave][lane] = fs;
+        sm.m_s[wave][lane] = fminf(fs, s_in);
     } else {
         sm.m_m[wave][lane] = INFINITY;
         sm.m_s[wave][lane] = INFINITY;
@@ -298,9 +370,6 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
             }
             bool ambiguous = false;
             if (staged && bpos != POS_NONE) {
-                const pcr_pt b = gv.pts[bpos];
-                bd2 = dist2(ax, ay, az, b);  // exact, direct form
-                bid = b.id;
                 // coordinate error of the filter: |local coordinate| <= R, binary32 conversion + subtraction
                 const double cellL = gv.cell0 * (double)(1ll << (2 * level));
                 const double R = 0.5 * cellL * (double)max(sm.dims[0], max(sm.dims[1], sm.dims[2]));
@@ -308,6 +377,16 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
                 const double dhi = sqrt((double)M * (1.0 + 1e-6)) + e;
                 const double U = (dhi + e) * (dhi + e) * (1.0 + 1e-6);
                 ambiguous = (double)S <= U;
+                if (res_d2) {
+                    const pcr_pt b = gv.pts[bpos];
+                    bd2 = dist2(ax, ay, az, b);  // exact, direct form (the nn1 API reports it)
+                    bid = b.id;
+                } else {
+                    // ICP pass: the epilogue recomputes the exact distance from the matched record anyway, so the
+                    // dependent 32-byte read is skipped here; U bounds the winner's true squared distance from above,
+                    // which is all the in-box test and the hard stage's first bound need
+                    bd2 = U;
+                }
             }
             if (clamped || !staged) {
                 unres = true;  // nothing usable is known about this query yet
@@ -340,7 +419,8 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         n_unres = __popcll(m);
         if (m) {
             unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(hard_count, n_unres);
+            const unsigned int hl = blockIdx.x % H_NLIST;
+            if (lane == 0) base = hl * hard_list_cap(nq) + atomicAdd(hard_count + H_CSTRIDE * hl, n_unres);
             base = __shfl(base, 0, 64);
             if (unres) {
                 work_item it;
@@ -484,15 +564,26 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
 }
 
 __global__ void __launch_bounds__(256)
-grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ count_p, double max_d2, int gated,
+grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ count_p, long long nq, double max_d2, int gated,
                  unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, unsigned long long* __restrict__ dbg) {
     __shared__ hard_lds s_lds[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     hard_lds* L = &s_lds[wave];
-    const unsigned int count = *count_p;
+    // exclusive prefix of the sub-list lengths (lanes 0..H_NLIST-1 hold one list each)
+    unsigned int l_cnt = lane < H_NLIST ? count_p[H_CSTRIDE * lane] : 0u;
+    unsigned int l_inc = l_cnt;
+#pragma unroll
+    for (int off = 1; off < H_NLIST; off <<= 1) {
+        const unsigned int o = __shfl_up(l_inc, off, 64);
+        if (lane >= off) l_inc += o;
+    }
+    const unsigned int count = __shfl(l_inc, H_NLIST - 1, 64);
+    const unsigned int l_exc = l_inc - l_cnt;
+    const unsigned int l_cap = hard_list_cap(nq);
     const int top = gv.levels - 1;
     for (unsigned int w = blockIdx.x * 4 + wave; w < count; w += gridDim.x * 4) {
-        const work_item it = list[w];
+        const int hl = (int)__ffsll((long long)__ballot(lane < H_NLIST && l_exc <= w && w < l_exc + l_cnt)) - 1;  // exactly one list holds item w
+        const work_item it = list[(size_t)hl * l_cap + (w - __shfl(l_exc, hl, 64))];
         const unsigned long long h_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
         unsigned int h_steps = 0, h_pts = 0;
         const double ax = it.ax, ay = it.ay, az = it.az;
@@ -500,9 +591,11 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
         long long bid = ID_NONE;
         unsigned int bpos = POS_NONE;
         if (lane == 0 && it.best_pos != POS_NONE) {
-            bd2 = it.best_d2;
+            // it.best_d2 is only an upper bound of this candidate's distance (see the tile stage): take the exact one
             bpos = it.best_pos;
-            bid = gv.pts[bpos].id;
+            const pcr_pt b0 = gv.pts[bpos];
+            bd2 = dist2(ax, ay, az, b0);
+            bid = b0.id;
         }
         double bound2 = gated ? fmin(it.best_d2, max_d2) : it.best_d2;  // DBL_MAX when nothing bounds the search
         bool clamped = false;
@@ -623,7 +716,7 @@ __global__ void grid_finalize_nn1_kernel(pcr_grid_view gv, const pcr_pt* __restr
                                          const double* __restrict__ res_d2, double max_d2, int gated, int* __restrict__ idx_out,
                                          double* __restrict__ d2_out, unsigned int* __restrict__ hard_count) {
     const long long qi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi == 0) *hard_count = 0;  // next search starts with an empty list (stream-ordered)
+    if (qi < H_NLIST) hard_count[H_CSTRIDE * qi] = 0;  // next search starts with empty lists (stream-ordered)
     if (qi >= nq) return;
     const unsigned int pos = res_pos[qi];
     const double d2 = res_d2[qi];
@@ -715,11 +808,11 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             *ticket = 0;  // ready for the next launch (stream-ordered)
-            *hard_count = 0;
         }
     }
     __syncthreads();
     if (!s_last) return;
+    if (threadIdx.x < H_NLIST) hard_count[H_CSTRIDE * threadIdx.x] = 0;
     __shared__ double s_red[8][32];
     const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;  // 8 strided slices, then a fixed tree
     double v = 0.0;
@@ -760,7 +853,7 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
     const int nblocks = (int)((nq + TQ - 1) / TQ);
     if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * nq, (void**)&sc->res_pos))) return rc;
     if (want_d2 && (rc = pcr_dev_alloc(ctx, sizeof(double) * nq, (void**)&sc->res_d2))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(work_item) * (size_t)nq, (void**)&sc->hard_list))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(nq), (void**)&sc->hard_list))) return rc;
     sc->hard_count = hard_count;  // zero at context creation, reset by the epilogue kernels
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
@@ -773,7 +866,7 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
     const long long want = (nq + 3) / 4;
     const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
     hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, stream, idx->view, (const work_item*)sc->hard_list,
-                       (const unsigned int*)sc->hard_count, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug);
+                       (const unsigned int*)sc->hard_count, (long long)nq, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
@@ -781,7 +874,7 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
 static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
     pcr_dev_free(ctx, sc->res_pos, sizeof(unsigned int) * sc->nq);
     if (sc->res_d2) pcr_dev_free(ctx, sc->res_d2, sizeof(double) * sc->nq);
-    pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)sc->nq);
+    pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(sc->nq));
 }
 
 int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xform* x, double max_d2, int32_t* d_idx, double* d_d2) {
@@ -791,7 +884,7 @@ int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xf
     int rc = pcr_cloud_morton_sort(ctx, qc, idx->cell);
     if (rc) return rc;
     const int64_t nq = qc->n;
-    rc = grid_search_launch(ctx, idx, qc->d, nq, ctx->stream, ctx->d_counters + 96, x, 0, max_d2, gated, true, true, &sc);
+    rc = grid_search_launch(ctx, idx, qc->d, nq, ctx->stream, ctx->d_counters + PCR_HARD_COUNTERS, x, 0, max_d2, gated, true, true, &sc);
     if (rc) return rc;
     const int grid = (int)((nq + 255) / 256);
     hipLaunchKernelGGL(grid_finalize_nn1_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq,
@@ -816,7 +909,7 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     while (lanes > 1 && nq < (int64_t)lanes * 8192) --lanes;
     if (lanes <= 1) {
         grid_scratch sc;
-        rc = grid_search_launch(ctx, idx, qc->d, nq, ctx->stream, ctx->d_counters + 96, x, write_back, max_d2, gated, false, true, &sc);
+        rc = grid_search_launch(ctx, idx, qc->d, nq, ctx->stream, ctx->d_counters + PCR_HARD_COUNTERS, x, write_back, max_d2, gated, false, true, &sc);
         if (rc) return rc;
         int grid = (int)((nq + 1023) / 1024);  // four queries per thread
         if (grid > ctx->cu_count) grid = ctx->cu_count;
@@ -844,7 +937,7 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         if (q0 >= q1) break;
         ++used;
         hipStream_t st = ctx->lane_stream[l];
-        rc = grid_search_launch(ctx, idx, qc->d + q0, q1 - q0, st, ctx->d_counters + 96 + 4 * l, x, write_back, max_d2, gated, false, false, &sc[l]);
+        rc = grid_search_launch(ctx, idx, qc->d + q0, q1 - q0, st, ctx->d_counters + PCR_HARD_COUNTERS + 1024 * l, x, write_back, max_d2, gated, false, false, &sc[l]);
         if (rc) break;
         int grid = (int)((q1 - q0 + 1023) / 1024);
         if (grid > ctx->cu_count) grid = ctx->cu_count;

@@ -31,6 +31,16 @@ struct pcr_cell_slot {  // 16 B open-addressing slot: Morton key of a cell -> [s
     unsigned int end;
 };
 
+// 32-B slot of the block table: a 2x2x2 block of level-l cells.  The 8 children are consecutive runs of the sorted
+// cloud (Morton order), so one slot = one cache line read answers 8 cell lookups: child c starts at
+// start + sum(cnt[0..c)).  flags != 0: some child holds >= 65535 points, use the per-cell table for this block.
+struct __attribute__((aligned(32))) pcr_block_slot {
+    unsigned long long key;  // packed block coordinates (cell >> 1); PCR_EMPTY_KEY = free
+    unsigned int start;
+    unsigned int flags;
+    unsigned short cnt[8];
+};
+
 // Device view of the multi-level voxel-hash grid over one target cloud.
 struct pcr_grid_view {
     const pcr_pt* pts;  // target points sorted by level-0 Morton key (id = original index)
@@ -41,6 +51,8 @@ struct pcr_grid_view {
     double inv_cell0;
     const pcr_cell_slot* table[PCR_MAX_LEVELS];
     unsigned int mask[PCR_MAX_LEVELS];  // capacity-1 (power of two)
+    const pcr_block_slot* btable[PCR_MAX_LEVELS];  // 2x2x2-block tables (linear probing by slot)
+    unsigned int bmask[PCR_MAX_LEVELS];
     double origin[3];                   // shift origin for moment accumulation (bbox centre)
 };
 
@@ -59,6 +71,8 @@ struct pcr_index {
     pcr_pt* sorted = nullptr;
     pcr_cell_slot* tables[PCR_MAX_LEVELS] = {nullptr};
     unsigned int caps[PCR_MAX_LEVELS] = {0};
+    pcr_block_slot* btables[PCR_MAX_LEVELS] = {nullptr};
+    unsigned int bcaps[PCR_MAX_LEVELS] = {0};
     pcr_grid_view view;
     // BRUTE (f64 MFMA operand layout): tiles of 16 targets, 64 doubles per tile in lane order
     double* mfma_a = nullptr;   // [n_tiles][64]
@@ -111,6 +125,10 @@ PCR_HIDDEN void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes);
 // records of a cloud in caller row order (the device copy may be Morton-reordered)
 PCR_HIDDEN int pcr_cloud_rows(pcr_ctx* ctx, const pcr_cloud* c, pcr_pt* d_out);
 constexpr int PCR_MAX_LANES = 4;
+// d_counters: words 0..1023 small per-subsystem counters; from word 1024 on, 1024 words per search lane for the
+// hard-list counters (32 counters, one per 128-byte line)
+constexpr int PCR_HARD_COUNTERS = 1024;
+constexpr size_t PCR_COUNTER_BYTES = 4 * (1024 + 1024 * 4);
 PCR_HIDDEN int pcr_ctx_lanes(pcr_ctx* ctx, int lanes);  // creates the lane streams on first use
 PCR_HIDDEN int pcr_ensure_scratch(pcr_ctx* ctx, size_t partial_bytes);
 PCR_HIDDEN void pcr_xform_from_T(const double* T, pcr_xform* x);
