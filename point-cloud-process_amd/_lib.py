@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcr.so")
+LIB_PATH = os.environ.get("PCR_LIB_PATH") or os.path.join(_HERE, "libpcr.so")  # override: A/B builds only
 
 PCR_OK = 0
 PCR_E_TOO_FEW_ASSOC = 1

@@ -51,6 +51,9 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
     c->h_pinned_bytes = 4096;
     c->zero_copy = getenv("PCR_NO_ZEROCOPY") == nullptr;
     if (const char* l = getenv("PCR_ICP_LANES")) c->icp_lanes = atoi(l) < 1 ? 1 : atoi(l);
+    if (c->zero_copy && getenv("PCR_NO_HOSTSUM") == nullptr &&
+        hipHostMalloc((void**)&c->h_slabs, sizeof(double) * PCR_NMOM * PCR_SLABS_PER_LANE * PCR_MAX_LANES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+        c->h_slabs = nullptr;
     if (hipHostMalloc((void**)&c->h_pinned, c->h_pinned_bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         delete c;
         return PCR_E_NOMEM;
@@ -73,6 +76,7 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     if (c->d_partials) hipFree(c->d_partials);
     if (c->d_counters) hipFree(c->d_counters);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->h_slabs) hipHostFree(c->h_slabs);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipEventDestroy(c->ev2);

@@ -563,6 +563,7 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
     }
 }
 
+// (115 VGPRs -> 4 waves per SIMD; forcing 5, 6 or 8 with amdgpu_waves_per_eu spills and measured 31, 39, 50 us against 29)
 __global__ void __launch_bounds__(256)
 grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ count_p, long long nq, double max_d2, int gated,
                  unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, unsigned long long* __restrict__ dbg) {
@@ -793,6 +794,12 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
         const double v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
         partials[(long long)blockIdx.x * PCR_NMOM + threadIdx.x] = v;
     }
+    if (ticket == nullptr) {
+        // host-sum mode: `partials` is pinned host memory; the host adds the slabs after the stream sync (no ticket,
+        // no last-block pass: two dependent round trips fewer on the critical path of an ICP iteration)
+        if (blockIdx.x == 0 && threadIdx.x < H_NLIST) hard_count[H_CSTRIDE * threadIdx.x] = 0;
+        return;
+    }
     // ---- the block that arrives last sums the slabs in fixed order (saves a launch boundary).
     // Hand-off per the CDNA4 recipe: drained stores -> barrier -> agent-scope release -> ticket;
     // last arriver: agent-scope acquire -> barrier -> plain loads.
@@ -904,10 +911,13 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     // Lanes: the pass over one pair is a chain of three dependent launches and is latency-bound; runs of the sorted
     // source are independent, so they go down separate streams and overlap each other's stalls.  Every lane reduces its
     // own moments (fixed order); the host adds the lanes in lane order.  One lane while profiling (per-kernel events).
-    int lanes = ctx->profile ? 1 : ctx->icp_lanes;
+    // Host-sum mode (the ICP loop's zero-copy read-back, not while profiling): every block's partial slab goes straight
+    // to pinned host memory and the host adds them after the sync.
+    const bool host_sum = (d_moments == ctx->h_pinned) && !ctx->profile && ctx->h_slabs != nullptr;
+    int lanes = host_sum ? ctx->icp_lanes : 1;
     if (lanes > PCR_MAX_LANES) lanes = PCR_MAX_LANES;
     while (lanes > 1 && nq < (int64_t)lanes * 8192) --lanes;
-    if (lanes <= 1) {
+    if (!host_sum) {
         grid_scratch sc;
         rc = grid_search_launch(ctx, idx, qc->d, nq, ctx->stream, ctx->d_counters + PCR_HARD_COUNTERS, x, write_back, max_d2, gated, false, true, &sc);
         if (rc) return rc;
@@ -928,37 +938,45 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     }
     if ((rc = pcr_ctx_lanes(ctx, lanes))) return rc;
     if (!was_sorted) PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sort ran on the main stream
-    if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)ctx->cu_count * lanes))) return rc;
     grid_scratch sc[PCR_MAX_LANES];
+    int grids[PCR_MAX_LANES];
     const int64_t per = ((nq + lanes - 1) / lanes + 1023) / 1024 * 1024;
     int used = 0;
     for (int l = 0; l < lanes && rc == PCR_OK; ++l) {
         const int64_t q0 = per * l, q1 = q0 + per < nq ? q0 + per : nq;
         if (q0 >= q1) break;
         ++used;
-        hipStream_t st = ctx->lane_stream[l];
+        hipStream_t st = lanes == 1 ? ctx->stream : ctx->lane_stream[l];
         rc = grid_search_launch(ctx, idx, qc->d + q0, q1 - q0, st, ctx->d_counters + PCR_HARD_COUNTERS + 1024 * l, x, write_back, max_d2, gated, false, false, &sc[l]);
         if (rc) break;
         int grid = (int)((q1 - q0 + 1023) / 1024);
-        if (grid > ctx->cu_count) grid = ctx->cu_count;
+        if (grid > PCR_SLABS_PER_LANE) grid = PCR_SLABS_PER_LANE;
+        grids[l] = grid;
+        // slabs go straight to pinned host memory; no ticket
         hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, st, idx->view, (const pcr_pt*)(qc->d + q0), (long long)(q1 - q0), *x,
                            write_back ? 0 : 1, (const unsigned int*)sc[l].res_pos, max_d2, gated ? 1 : 0,
-                           ctx->d_partials + (size_t)PCR_NMOM * ctx->cu_count * l, ctx->d_counters + 64 + 8 * l, ctx->h_pinned + 32 * (l + 1),
-                           sc[l].hard_count);
+                           ctx->h_slabs + (size_t)PCR_NMOM * PCR_SLABS_PER_LANE * l, (unsigned int*)nullptr, (double*)nullptr, sc[l].hard_count);
     }
     hipError_t e = hipGetLastError();
     for (int l = 0; l < used; ++l) {
-        const hipError_t es = hipStreamSynchronize(ctx->lane_stream[l]);
+        const hipError_t es = hipStreamSynchronize(lanes == 1 ? ctx->stream : ctx->lane_stream[l]);
         if (e == hipSuccess) e = es;
         grid_scratch_free(ctx, &sc[l]);
     }
     if (rc) return rc;
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
+    // fixed-order sum on the host: lanes in order, slabs in order, 8 interleaved accumulators then a fixed tree
     double m[PCR_NMOM];
-    for (int k = 0; k < PCR_NMOM; ++k) {
-        double v = 0.0;
-        for (int l = 0; l < used; ++l) v += ctx->h_pinned[32 * (l + 1) + k];
-        m[k] = v;
+    for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+    for (int l = 0; l < used; ++l) {
+        const double* slab = ctx->h_slabs + (size_t)PCR_NMOM * PCR_SLABS_PER_LANE * l;
+        double acc[8][PCR_NMOM];
+        for (int j = 0; j < 8; ++j)
+            for (int k = 0; k < PCR_NMOM; ++k) acc[j][k] = 0.0;
+        for (int b2 = 0; b2 < grids[l]; ++b2)
+            for (int k = 0; k < PCR_NMOM; ++k) acc[b2 & 7][k] += slab[(size_t)b2 * PCR_NMOM + k];
+        for (int k = 0; k < PCR_NMOM; ++k)
+            m[k] += ((acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k])) + ((acc[4][k] + acc[5][k]) + (acc[6][k] + acc[7][k]));
     }
     // hand the sum over the way the single-lane pass does (the caller reads h_pinned, or copies d_moments)
     if (d_moments == ctx->h_pinned) memcpy(ctx->h_pinned, m, sizeof(m));

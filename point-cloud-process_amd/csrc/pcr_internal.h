@@ -95,6 +95,7 @@ struct pcr_ctx {
     size_t h_pinned_bytes = 0;
     int icp_lanes = 1;                    // runs of the source searched on separate streams per ICP pass (PCR_ICP_LANES)
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* h_slabs = nullptr;            // pinned, device-mapped: per-block moment slabs of the host-sum ICP pass
     bool zero_copy = true;  // kernels write small results straight into h_pinned (PCR_NO_ZEROCOPY=1 disables)
     // device scratch for per-block partial moments
     double* d_partials = nullptr;
@@ -125,6 +126,7 @@ PCR_HIDDEN void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes);
 // records of a cloud in caller row order (the device copy may be Morton-reordered)
 PCR_HIDDEN int pcr_cloud_rows(pcr_ctx* ctx, const pcr_cloud* c, pcr_pt* d_out);
 constexpr int PCR_MAX_LANES = 4;
+constexpr int PCR_SLABS_PER_LANE = 256;
 // d_counters: words 0..1023 small per-subsystem counters; from word 1024 on, 1024 words per search lane for the
 // hard-list counters (32 counters, one per 128-byte line)
 constexpr int PCR_HARD_COUNTERS = 1024;
