@@ -211,3 +211,22 @@ def test_icp_is_bitwise_reproducible(pcp, syn):
     idx0 = index.nn1(src)
     idx1 = index.nn1(src)
     assert np.array_equal(idx0[0], idx1[0]) and np.array_equal(idx0[1], idx1[1])
+
+
+def test_nn1_cell_with_more_than_65535_points(pcp, oracle):
+    """A level-0 cell holding > 65535 points overflows the 16-bit child counts of the 2x2x2-block table: the
+    directory must fall back to the per-cell table for that block (and the tile goes to the exact descent)."""
+    rng = np.random.default_rng(21)
+    blob = np.array([3.0, 3.0, 3.0]) + rng.uniform(0, 1e-3, (70000, 3))
+    rest = rng.uniform(0, 6.0, (30000, 3))
+    tgt = np.concatenate([rest[:15000], blob, rest[15000:]])
+    q = np.concatenate([np.array([3.0, 3.0, 3.0]) + rng.uniform(-0.05, 0.05, (3000, 3)), rng.uniform(-0.2, 6.2, (3000, 3))])
+    index = pcp.TargetIndex(tgt, kind="grid", cell=0.1)
+    idx, d2 = index.nn1(q)
+    ties = _check_nn(idx, d2, q, tgt, oracle)
+    assert ties < 50
+    # and through the fused ICP pass: same association count as the oracle's gate
+    m, o, s = index.moments(q, np.eye(4), max_d2=5.0)
+    oi, od2, _ = oracle.nn1_exact(q, tgt)
+    assert int(round(m[0])) == int((od2 < 5.0).sum())
+    assert abs(s - od2[od2 < 5.0].sum()) <= 1e-9 * max(1.0, od2.sum())
