@@ -1,0 +1,80 @@
+"""GPU: randomised parity sweep of the exact 1-NN grid path (tile directory through the block tables, grouped filter,
+hard stage) and of the fused ICP moments against the CPU oracle -- shapes, densities, cell sizes and offsets the fixed
+tests do not cover.  Every case is seeded; distances must be bit-identical, indices equal outside exact ties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIE_MARGIN = 1e-12
+
+
+def _cloud(rng, kind, n):
+    if kind == "uniform":
+        return rng.uniform(-5, 5, (n, 3))
+    if kind == "plane":
+        p = rng.uniform(-20, 20, (n, 3))
+        p[:, 2] = 0.01 * rng.normal(size=n)
+        return p
+    if kind == "line":
+        t = rng.uniform(-50, 50, n)
+        return np.c_[t, 0.3 * t + 1e-3 * rng.normal(size=n), 2.0 + 1e-3 * rng.normal(size=n)]
+    if kind == "clusters":
+        c = rng.uniform(-30, 30, (12, 3))
+        return c[rng.integers(0, 12, n)] + rng.normal(0, 0.05, (n, 3)) * rng.uniform(0.1, 10, (n, 1))
+    if kind == "shell":
+        v = rng.normal(size=(n, 3))
+        return 25.0 * v / np.linalg.norm(v, axis=1, keepdims=True) + rng.normal(0, 0.02, (n, 3))
+    if kind == "lattice":  # many exact ties
+        g = rng.integers(0, 12, (n, 3)).astype(np.float64) * 0.25
+        return g
+    raise ValueError(kind)
+
+
+CASES = [
+    # kind, n_tgt, n_q, cell (0 = automatic), offset, query spread
+    ("uniform", 1, 50, 0.0, 0.0, 1.0), ("uniform", 2, 50, 0.0, 0.0, 1.0), ("uniform", 3, 64, 0.0, 0.0, 1.0),
+    ("uniform", 63, 63, 0.0, 0.0, 1.0), ("uniform", 64, 65, 0.0, 0.0, 1.0), ("uniform", 65, 1, 0.0, 0.0, 1.0),
+    ("uniform", 5000, 4097, 0.0, 0.0, 1.2), ("uniform", 5000, 3000, 0.01, 0.0, 1.0), ("uniform", 5000, 3000, 50.0, 0.0, 1.0),
+    ("plane", 30000, 9000, 0.0, 0.0, 1.0), ("plane", 30000, 9000, 0.05, 1.0e5, 1.0), ("line", 20000, 5000, 0.0, 0.0, 1.0),
+    ("clusters", 40000, 10000, 0.0, 0.0, 1.0), ("clusters", 40000, 10000, 0.02, -3.0e4, 1.5), ("shell", 25000, 8000, 0.0, 0.0, 0.9),
+    ("shell", 25000, 8000, 1.0, 0.0, 2.0), ("lattice", 8000, 4000, 0.0, 0.0, 1.0), ("lattice", 8000, 4000, 0.1, 7.0e3, 1.1),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_nn1_fuzz(pcp, oracle, case):
+    kind, n_t, n_q, cell, off, spread = CASES[case]
+    rng = np.random.default_rng(1000 + case)
+    tgt = _cloud(rng, kind, n_t) + off
+    # queries: a mix of perturbed target points, points of the same distribution, and far outliers
+    a = tgt[rng.integers(0, n_t, n_q // 2)] + rng.normal(0, 0.03, (n_q // 2, 3))
+    b = (_cloud(rng, kind, n_q - n_q // 2) * spread) + off
+    q = np.concatenate([a, b])
+    if n_q >= 100:
+        q[:5] += 500.0          # far outside the grid
+        q[5:10] = tgt[:5] if n_t >= 5 else q[5:10]   # exact hits (distance 0)
+    index = pcp.TargetIndex(tgt, kind="grid", cell=cell)
+    idx, d2 = index.nn1(q)
+    oi, od2, margin = oracle.nn1_exact(q, tgt)
+    assert np.array_equal(d2, od2), (kind, n_t, cell)
+    clear = margin > TIE_MARGIN
+    assert np.array_equal(idx[clear], oi[clear])
+    # on exact ties the lowest index wins
+    tie = ~clear
+    if tie.any():
+        dd = ((q[tie][:, None, :] - tgt[None, :, :]) ** 2)
+        dm = (dd[..., 0] + dd[..., 1]) + dd[..., 2]
+        exact_tie = (dm == od2[tie][:, None])
+        assert np.array_equal(idx[tie], exact_tie.argmax(axis=1))
+    # gated + transformed pass through the fused ICP kernels
+    T = np.eye(4)
+    T[:3, 3] = rng.normal(0, 0.05, 3)
+    gate = float(np.quantile(od2, 0.8)) if n_q > 10 else 0.0
+    if gate > 0:
+        m, o, s = index.moments(q, T, max_d2=gate)
+        qt = q + T[:3, 3]
+        _, od2t, _ = oracle.nn1_exact(qt, tgt)
+        keep = od2t < gate
+        assert int(round(m[0])) == int(keep.sum())
+        assert abs(s - od2t[keep].sum()) <= 1e-9 * max(1.0, od2t[keep].sum())
