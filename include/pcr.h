@@ -237,6 +237,15 @@ PCR_API int pcr_ransac_default_params(pcr_ransac_params* p);
 PCR_API int pcr_ransac(pcr_ctx* ctx, const pcr_cloud* source, const pcr_cloud* target, const int32_t* corr, int64_t m,
                        const pcr_ransac_params* params, pcr_ransac_result* result);
 
+/* ------------------------------------------------------------------ DBSCAN
+ * DBSCAN.fit (Cluster_dbscan/dbscan.py:10-36), a consumer of the radius query:
+ * labels_out[n] = cluster id per row (-1 noise), numbered in the reference's
+ * discovery order (seeds taken from the END of the index list; a seed needs
+ * >= min_pts neighbours, a reached point expands only with > min_pts; a point
+ * first met as a noise seed stays noise).  Neighbourhood = distance <= radius,
+ * the point itself included (scipy query_ball_point).                        */
+PCR_API int pcr_dbscan(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int min_pts, int32_t* labels_out, int32_t* n_clusters_out);
+
 /* ------------------------------------------------------------- timing aid
  * HIP-event stopwatch on the ctx stream, for bench.py's roofline figures.   */
 PCR_API int pcr_timer_start(pcr_ctx* ctx);

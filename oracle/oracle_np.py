@@ -315,3 +315,35 @@ def normals(points, k=5):
         w, v = pca(pts[nbr[i]])
         out[i], evs[i] = v[:, 2], w
     return out, evs, nbr
+
+
+# ------------------------------------------------------------------ DBSCAN
+def dbscan(data, radius=0.5, min_pts=10):
+    """Cluster_dbscan/dbscan.py:10-36 with a visited mask instead of the O(N) list membership tests (same traversal):
+    seeds from the END of the index list (:18), seed needs >= Min_Pts (:20), reached points expand with > Min_Pts (:32),
+    a point popped as a noise seed is never relabelled (:21-22,29).  Pinned by tests/golden/dbscan.npz."""
+    pts = np.asarray(data, dtype=np.float64)
+    tree = cKDTree(pts)
+    nbrs = tree.query_ball_point(pts, radius)
+    n = len(pts)
+    labels = -np.ones(n, dtype=np.int32)
+    visited = np.zeros(n, dtype=bool)
+    label = -1
+    for ind in range(n - 1, -1, -1):
+        if visited[ind]:
+            continue
+        visited[ind] = True
+        if len(nbrs[ind]) < min_pts:
+            continue
+        label += 1
+        labels[ind] = label
+        stack = list(nbrs[ind])
+        while stack:
+            cur = stack.pop()
+            if visited[cur]:
+                continue
+            visited[cur] = True
+            labels[cur] = label
+            if len(nbrs[cur]) > min_pts:
+                stack.extend(nbrs[cur])
+    return labels

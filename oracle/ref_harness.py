@@ -429,6 +429,28 @@ def gen_pca(syn):
     np.savez_compressed(os.path.join(GOLD, "pca_normals.npz"), **out)
 
 
+# --------------------------------------------------------------------------
+# G8: DBSCAN (Cluster_dbscan/dbscan.py) -- imports only scipy + numpy
+# --------------------------------------------------------------------------
+def gen_dbscan(syn):
+    ref = import_ref("Cluster_dbscan", "dbscan")
+    rng = np.random.default_rng(81)
+    out = {}
+    blobs = np.concatenate([c + rng.normal(0, s, (n, 3)) for c, s, n in
+                            [((0, 0, 0), 0.15, 500), ((3, 0, 0), 0.3, 700), ((0, 4, 1), 0.1, 300), ((1.5, 0, 0), 0.25, 200)]]
+                           + [rng.uniform(-3, 7, (300, 3))])
+    rng.shuffle(blobs)
+    scan = syn.kitti_like_scan(2500, seed=12).astype(np.float64)
+    for tag, pts, r, m in (("blobs", blobs, 0.3, 10), ("blobs_tight", blobs, 0.12, 4), ("scan", scan, 1.0, 6)):
+        d = ref.DBSCAN(radius=r, Min_Pts=m)
+        d.fit(pts)
+        out[tag + "_pts"] = pts
+        out[tag + "_labels"] = d.predict()
+        out[tag + "_param"] = np.array([r, m])
+        print("dbscan %-12s n=%d clusters=%d noise=%d" % (tag, len(pts), d.predict().max() + 1, (d.predict() < 0).sum()))
+    np.savez_compressed(os.path.join(GOLD, "dbscan.npz"), **out)
+
+
 def ev_tq(T):
     """t, q (w first) of a pose for the result files (same convention as main.py:170-174, via scipy)."""
     from scipy.spatial.transform import Rotation
@@ -458,6 +480,8 @@ def main():
         gen_eval(syn)
     if a.only in ("", "pca"):
         gen_pca(syn)
+    if a.only in ("", "dbscan"):
+        gen_dbscan(syn)
 
 
 if __name__ == "__main__":

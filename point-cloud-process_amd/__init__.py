@@ -46,6 +46,7 @@ from .global_registration import (  # noqa: F401
     registration_ransac_based_on_feature_matching,
     voxel_down_sample,
 )
+from .dbscan import DBSCAN  # noqa: F401
 from .batch import register_batch, shard_range  # noqa: F401
 from . import evaluate  # noqa: F401
 from .evaluate import evaluate_rt, get_P_diff, is_registration_successful  # noqa: F401

@@ -136,6 +136,7 @@ SIGNATURES = {
     "pcr_feature_match": (C.c_int, [_vp, _dp, C.c_int64, _dp, C.c_int64, C.c_int, _ip, _dp]),
     "pcr_ransac_default_params": (C.c_int, [C.POINTER(RansacParams)]),
     "pcr_ransac": (C.c_int, [_vp, _vp, _vp, _ip, C.c_int64, C.POINTER(RansacParams), C.POINTER(RansacResult)]),
+    "pcr_dbscan": (C.c_int, [_vp, _vp, C.c_double, C.c_int, _ip, _ip]),
     "pcr_debug_read": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int64]),
     "pcr_profile_enable": (C.c_int, [_vp, C.c_int]),
     "pcr_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),

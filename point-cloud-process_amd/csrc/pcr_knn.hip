@@ -297,4 +297,81 @@ int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries, int6
     return PCR_OK;
 }
 
+
+// DBSCAN.fit of Cluster_dbscan/dbscan.py:10-36 -- a consumer of the radius query.  All N radius queries
+// run on the device (count pass + fill pass of radius_kernel); the labelling loop is the reference's own sequential
+// traversal, run on the host over the neighbour lists, so labels match the reference's including its quirks: seeds are
+// popped from the END of the index list, a seed needs >= min_pts neighbours (self included) but a reached point only
+// expands with > min_pts, and a point first popped as a noise seed is never relabelled.
+int pcr_dbscan(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int min_pts, int32_t* labels_out, int32_t* n_clusters_out) {
+    if (!ctx || !cloud || !labels_out || !(radius >= 0)) return PCR_E_INVALID;
+    const int64_t n = cloud->n;
+    if (n <= 0) return PCR_E_EMPTY;
+    hipSetDevice(ctx->device);
+    std::vector<double> xyz(3 * (size_t)n);
+    int rc = pcr_cloud_download_f64(ctx, cloud, xyz.data());
+    if (rc) return rc;
+    pcr_index* index = nullptr;
+    if ((rc = pcr_index_build(ctx, cloud, PCR_INDEX_GRID, radius > 0 ? radius : 0.0, &index))) return rc;
+    double* d_q = nullptr;
+    long long *d_counts = nullptr, *d_offs = nullptr;
+    int* d_idx = nullptr;
+    double* d_dist = nullptr;
+    std::vector<long long> counts((size_t)n), offs((size_t)n + 1, 0);
+    std::vector<int> nbr;
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    do {
+        if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 3 * n, (void**)&d_q))) break;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(long long) * n, (void**)&d_counts))) break;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(long long) * (n + 1), (void**)&d_offs))) break;
+        hipMemcpyAsync(d_q, xyz.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
+        hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)n, radius, d_counts,
+                           (const long long*)nullptr, (int*)nullptr, (double*)nullptr);
+        hipMemcpyAsync(counts.data(), d_counts, sizeof(long long) * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
+        for (int64_t i = 0; i < n; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + counts[(size_t)i];
+        const long long total = offs[(size_t)n];
+        if ((rc = pcr_dev_alloc(ctx, sizeof(int) * (total + 1), (void**)&d_idx))) break;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(double) * (total + 1), (void**)&d_dist))) break;
+        hipMemcpyAsync(d_offs, offs.data(), sizeof(long long) * (n + 1), hipMemcpyHostToDevice, ctx->stream);
+        hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)n, radius,
+                           (long long*)nullptr, (const long long*)d_offs, d_idx, d_dist);
+        nbr.resize((size_t)total + 1);
+        hipMemcpyAsync(nbr.data(), d_idx, sizeof(int) * total, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
+        pcr_dev_free(ctx, d_idx, sizeof(int) * (total + 1));
+        pcr_dev_free(ctx, d_dist, sizeof(double) * (total + 1));
+        d_idx = nullptr; d_dist = nullptr;
+    } while (0);
+    if (d_q) pcr_dev_free(ctx, d_q, sizeof(double) * 3 * n);
+    if (d_counts) pcr_dev_free(ctx, d_counts, sizeof(long long) * n);
+    if (d_offs) pcr_dev_free(ctx, d_offs, sizeof(long long) * (n + 1));
+    pcr_index_free(ctx, index);
+    if (rc) return rc;
+    // dbscan.py:17-34
+    std::vector<char> visited((size_t)n, 0);
+    std::vector<int> stack;
+    int label = -1;
+    for (int64_t i = 0; i < n; ++i) labels_out[i] = -1;
+    for (int64_t ind = n - 1; ind >= 0; --ind) {           // unvisited.pop()
+        if (visited[(size_t)ind]) continue;
+        visited[(size_t)ind] = 1;
+        if (counts[(size_t)ind] < min_pts) continue;       // noise (for good: it left `unvisited`)
+        ++label;
+        labels_out[ind] = label;
+        stack.assign(nbr.begin() + offs[(size_t)ind], nbr.begin() + offs[(size_t)ind + 1]);
+        while (!stack.empty()) {
+            const int cur = stack.back();
+            stack.pop_back();
+            if (visited[(size_t)cur]) continue;            // `if cur_ind in unvisited`
+            visited[(size_t)cur] = 1;
+            labels_out[cur] = label;
+            if (counts[(size_t)cur] > min_pts)             // strict, unlike the seed test
+                stack.insert(stack.end(), nbr.begin() + offs[(size_t)cur], nbr.begin() + offs[(size_t)cur + 1]);
+        }
+    }
+    if (n_clusters_out) *n_clusters_out = label + 1;
+    return PCR_OK;
+}
+
 }  // extern "C"

@@ -76,6 +76,18 @@ class KDTreeFlann:
         return [kk, idx[0, :kk].tolist(), (dist[0, :kk] ** 2).tolist()]
 
     def search_radius_vector_3d(self, query, radius):
+        """-> [k, idx list, SQUARED distance list], ascending distance (Final_Project/scripts/extract.py:519-524)."""
+        q = np.asarray(query, dtype=np.float64).reshape(1, 3)
+        _, idx, dist = self.index.radius(q, float(radius))
+        return [len(idx), idx.tolist(), (dist ** 2).tolist()]
+
+    def search_hybrid_vector_3d(self, query, radius, max_nn):
+        """-> the max_nn nearest of the radius result (Open3D KDTreeSearchParamHybrid)."""
+        k, idx, d2 = self.search_radius_vector_3d(query, radius)
+        k = min(k, int(max_nn))
+        return [k, idx[:k], d2[:k]]
+
+    def search_radius_vector_3d(self, query, radius):
         q = np.asarray(query, dtype=np.float64).reshape(1, 3)
         off, idx, dist = self.index.radius(q, float(radius))
         return [int(off[1]), idx.tolist(), (dist ** 2).tolist()]

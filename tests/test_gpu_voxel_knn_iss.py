@@ -136,3 +136,28 @@ def test_register_batch_single_gpu_streams(pcp, oracle, syn):
         ref = oracle.icp_point2point(s6[:, :3], t6[:, :3], np.eye(4))
         assert r["iters"] == ref["iters"]
         assert np.linalg.norm(r["T"] - ref["T"]) < 1e-9
+
+
+def test_dbscan_matches_reference_labels(pcp, oracle, syn):
+    """Cluster_dbscan/dbscan.py: labels equal the reference's own output (goldens), numbering and noise quirks included."""
+    g = load_golden("dbscan.npz")
+    for tag in ("blobs", "blobs_tight", "scan"):
+        r, m = g[f"{tag}_param"]
+        d = pcp.DBSCAN(radius=float(r), Min_Pts=int(m))
+        d.fit(g[f"{tag}_pts"])
+        assert d.predict().dtype == np.int32
+        assert np.array_equal(d.predict(), g[f"{tag}_labels"]), tag
+    pts = syn.kitti_like_scan(60000, seed=6).astype(np.float64)
+    d = pcp.DBSCAN(radius=0.6, Min_Pts=8)
+    d.fit(pts)
+    assert np.array_equal(d.predict(), oracle.dbscan(pts, 0.6, 8))
+
+
+def test_kdtreeflann_radius_search(pcp, oracle, syn):
+    pts = syn.kitti_like_scan(20000, seed=7).astype(np.float64)
+    tree = pcp.KDTreeFlann(pcp.PointCloud(pts))
+    k, idx, d2 = tree.search_radius_vector_3d(pts[123] + 0.01, 1.5)
+    ref = np.flatnonzero(np.linalg.norm(pts - (pts[123] + 0.01), axis=1) <= 1.5)
+    assert k == len(ref) and set(idx) == set(ref.tolist()) and np.all(np.diff(d2) >= 0)
+    k2, idx2, _ = tree.search_hybrid_vector_3d(pts[123] + 0.01, 1.5, 10)
+    assert k2 == min(10, k) and idx2 == idx[:k2]

@@ -135,3 +135,10 @@ def test_pca_and_normals_match_reference(oracle):
         check_pca(w, v, g[f"{tag}_w"], g[f"{tag}_v"])
         nrm, evs, nbr = oracle.normals(pts, 5)
         check_normals(pts, nrm, evs, nbr, g[f"{tag}_normals"], g[f"{tag}_evs"], g[f"{tag}_nbrs"])
+
+
+def test_dbscan_matches_reference(oracle):
+    g = load_golden("dbscan.npz")
+    for tag in ("blobs", "blobs_tight", "scan"):
+        r, m = g[f"{tag}_param"]
+        assert np.array_equal(oracle.dbscan(g[f"{tag}_pts"], float(r), int(m)), g[f"{tag}_labels"]), tag
