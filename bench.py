@@ -186,6 +186,9 @@ def main():
         ctx.sync()
 
     run_icp_steps(pkg, index, src, a.warmup, ctx)  # untimed warm-up
+    if dist is not None:  # warm the collective too (communicator and kernel set-up are one-off costs)
+        wrec = torch.zeros(18, dtype=torch.float64, device=tdev)
+        dist.all_gather([torch.zeros_like(wrec) for _ in range(world)], wrec)
     barrier()
     t0 = time.perf_counter()
     r = run_icp_steps(pkg, index, src, a.steps, ctx)
