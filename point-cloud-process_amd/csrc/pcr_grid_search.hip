@@ -96,14 +96,22 @@ struct tile_smem {
 
 __global__ void __launch_bounds__(256)
 grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
-                 int gated, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
+                 int gated, int xcd_remap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
                  unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg) {
     __shared__ tile_smem sm;
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_ph[5] = {0, 0, 0, 0, 0};
 #define PH_STAMP(i) do { if (dbg) t_ph[i] = __builtin_amdgcn_s_memtime() - t_start; } while (0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long qi = (long long)blockIdx.x * TQ + lane;  // every wave holds the same 64 queries
+    // Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8), each XCD with its own L2: give every XCD one
+    // contiguous run of tiles (= one compact region of the scan), so that the hash slots and target records a tile needs
+    // are mostly those its neighbours on the same L2 already fetched.  PCR_TILE_XCD=0 restores the plain order.
+    unsigned int tile = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = gridDim.x >> 3, main = per << 3;  // the last gridDim.x % 8 tiles keep their index
+        if (tile < main) tile = (tile & 7u) * per + (tile >> 3);
+    }
+    const long long qi = (long long)tile * TQ + lane;  // every wave holds the same 64 queries
     const bool qvalid = qi < nq;
     // ---- load + transform the tile's queries (wave 0 writes back)
     double ax = 0, ay = 0, az = 0;
@@ -419,7 +427,7 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         n_unres = __popcll(m);
         if (m) {
             unsigned int base = 0;
-            const unsigned int hl = blockIdx.x % H_NLIST;
+            const unsigned int hl = tile % H_NLIST;
             if (lane == 0) base = hl * hard_list_cap(nq) + atomicAdd(hard_count + H_CSTRIDE * hl, n_unres);
             base = __shfl(base, 0, 64);
             if (unres) {
@@ -866,8 +874,9 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
     pcr_xform_from_T(nullptr, &xi);
     if (mark) pcr_prof_mark(ctx, 0);
     static const int dyn_lds = getenv("PCR_TILE_DYNLDS") ? atoi(getenv("PCR_TILE_DYNLDS")) : 0;  // experiment: caps blocks/CU
+    static const int xcd_remap = getenv("PCR_TILE_XCD") ? atoi(getenv("PCR_TILE_XCD")) : 1;
     hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), dyn_lds, stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
-                       write_back, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
+                       write_back, max_d2, gated ? 1 : 0, xcd_remap, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;
