@@ -29,7 +29,10 @@
 constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
 constexpr int T_MAXC = 1024;                // cells in a tile box
 constexpr int T_PMAX = 512;                 // points staged per round
-constexpr unsigned int T_PCAP = 4 * T_PMAX;   // tiles with more candidate points than this go per-query
+// Tiles with more candidate points than the cap go per-query to the hard stage.  The cap is chosen per launch: 4 rounds
+// (2048 points) when the grid is a single generation of blocks and a long tile would be the kernel's tail, 16 rounds when
+// there are several generations (a dense 1M-point scan sent 40 % of its queries to the hard stage with the small cap).
+constexpr unsigned int T_PCAP_SMALL = 4 * T_PMAX, T_PCAP_LARGE = 16 * T_PMAX;
 constexpr unsigned int HARD_SCAN_T = 192;   // the hard stage scans cells up to this size, descends into bigger ones
 constexpr int HARD_STACK = 160;
 constexpr long long ID_NONE = 0x7fffffffffffffffll;
@@ -96,7 +99,7 @@ struct tile_smem {
 
 __global__ void __launch_bounds__(256)
 grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
-                 int gated, int xcd_remap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
+                 int gated, int xcd_remap, unsigned int pcap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
                  unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg) {
     __shared__ tile_smem sm;
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -271,7 +274,7 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         // targets) and goes to the exact hard stage.
         float fm = INFINITY, fs = INFINITY;  // smallest / second smallest group minimum of the filter distances
         float s_in = INFINITY;               // runner-up inside the winner's own group
-        if (total <= T_PCAP) {
+        if (total <= pcap) {
             staged = true;
             const double cellL = gv.cell0 * (double)(1ll << (2 * level));
             const int blL = (int)(PCR_COORD_BIAS >> (2 * level));
@@ -875,8 +878,10 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
     if (mark) pcr_prof_mark(ctx, 0);
     static const int dyn_lds = getenv("PCR_TILE_DYNLDS") ? atoi(getenv("PCR_TILE_DYNLDS")) : 0;  // experiment: caps blocks/CU
     static const int xcd_remap = getenv("PCR_TILE_XCD") ? atoi(getenv("PCR_TILE_XCD")) : 1;
+    static const int pcap_env = getenv("PCR_TILE_PCAP") ? atoi(getenv("PCR_TILE_PCAP")) : 0;
+    const unsigned int pcap = pcap_env > 0 ? (unsigned int)pcap_env : (nblocks > 8 * ctx->cu_count ? T_PCAP_LARGE : T_PCAP_SMALL);
     hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), dyn_lds, stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
-                       write_back, max_d2, gated ? 1 : 0, xcd_remap, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
+                       write_back, max_d2, gated ? 1 : 0, xcd_remap, pcap, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;

@@ -5,13 +5,14 @@ os.environ["PCR_DEBUG_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pcp = importlib.import_module("point-cloud-process_amd")
 L = pcp._lib
-src, tgt, Tt = pcp.synthetic.perturbed_pair(120000, seed=0)
+NPTS = int(os.environ.get('N', 120000))
+src, tgt, Tt = pcp.synthetic.perturbed_pair(NPTS, seed=0)
 cell = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
 ctx = pcp.default_context()
 index = pcp.TargetIndex(tgt, kind="grid", cell=cell)
 sd = pcp.DeviceCloud.upload(src).prepare(index)
 r = pcp.icp_device(sd, index, np.eye(4), mode="total", max_iter=3, r_thres=-1, t_thres=-1, min_iter=3)
-nb = (120000 + 63) // 64
+nb = (NPTS + 63) // 64
 buf = np.zeros((1 << 16) + nb * 8, dtype=np.uint64)
 L.check(L.lib().pcr_debug_read(ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size))
 ph = buf[(1 << 16):].reshape(nb, 8)[:, :5].astype(np.float64)
