@@ -27,7 +27,7 @@
 #include "pcr_grid_dev.h"
 
 constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
-constexpr int T_MAXC = 1024;                // cells in a tile box
+constexpr int T_MAXC = 512;                 // cells in a tile box (1024: more sparse tiles stay at a fine level and leave their queries unresolved; 256 and below: boxes at the coarser level overflow the candidate cap)
 constexpr int T_PMAX = 512;                 // points staged per round
 // Tiles with more candidate points than the cap go per-query to the hard stage.  The cap is chosen per launch: 4 rounds
 // (2048 points) when the grid is a single generation of blocks and a long tile would be the kernel's tail, 16 rounds when
@@ -99,7 +99,7 @@ struct tile_smem {
 
 __global__ void __launch_bounds__(256)
 grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
-                 int gated, int xcd_remap, unsigned int pcap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
+                 int gated, int xcd_remap, unsigned int pcap, int maxc, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
                  unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg) {
     __shared__ tile_smem sm;
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -149,7 +149,7 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
                 for (int l = 0; l < gv.levels; ++l) {
                     const long long d0 = (mx[0] >> (2 * l)) - (mn[0] >> (2 * l)) + 3, d1 = (mx[1] >> (2 * l)) - (mn[1] >> (2 * l)) + 3,
                                     d2 = (mx[2] >> (2 * l)) - (mn[2] >> (2 * l)) + 3;
-                    if (d0 * d1 * d2 <= T_MAXC) {
+                    if (d0 * d1 * d2 <= (long long)maxc) {
                         level = l;
                         sm.box_lo[0] = (mn[0] >> (2 * l)) - 1; sm.box_lo[1] = (mn[1] >> (2 * l)) - 1; sm.box_lo[2] = (mn[2] >> (2 * l)) - 1;
                         sm.dims[0] = (int)d0; sm.dims[1] = (int)d1; sm.dims[2] = (int)d2;
@@ -878,10 +878,12 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
     if (mark) pcr_prof_mark(ctx, 0);
     static const int dyn_lds = getenv("PCR_TILE_DYNLDS") ? atoi(getenv("PCR_TILE_DYNLDS")) : 0;  // experiment: caps blocks/CU
     static const int xcd_remap = getenv("PCR_TILE_XCD") ? atoi(getenv("PCR_TILE_XCD")) : 1;
+    static const int maxc_env = getenv("PCR_TILE_MAXC") ? atoi(getenv("PCR_TILE_MAXC")) : 0;
+    const int maxc = maxc_env > 0 && maxc_env <= T_MAXC ? maxc_env : T_MAXC;
     static const int pcap_env = getenv("PCR_TILE_PCAP") ? atoi(getenv("PCR_TILE_PCAP")) : 0;
     const unsigned int pcap = pcap_env > 0 ? (unsigned int)pcap_env : (nblocks > 8 * ctx->cu_count ? T_PCAP_LARGE : T_PCAP_SMALL);
     hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), dyn_lds, stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
-                       write_back, max_d2, gated ? 1 : 0, xcd_remap, pcap, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
+                       write_back, max_d2, gated ? 1 : 0, xcd_remap, pcap, maxc, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;
