@@ -293,9 +293,11 @@ fpfh_kernel(long long n, int max_nn, const double* __restrict__ spfh, const unsi
 // One thread per query row, target rows staged through LDS in tiles; squared L2 summed over the
 // dimensions in order; ties to the lowest target row.
 constexpr int FM_TILE = 32;
+// grid = (query blocks, target splits): block (bx, by) scans targets [by * per, (by + 1) * per); a small merge kernel
+// takes the minimum over the splits (ascending split order + strict comparison keeps the lowest row on ties).
 template <int DIM>
 __global__ void __launch_bounds__(256) feature_match_kernel(const double* __restrict__ A, long long na, const double* __restrict__ B, long long nb, int dim_rt,
-                                                             int* __restrict__ idx_out, double* __restrict__ d2_out) {
+                                                             long long per, int* __restrict__ idx_out, double* __restrict__ d2_out) {
     extern __shared__ double tile[];  // FM_TILE * dim
     const int dim = DIM > 0 ? DIM : dim_rt;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,8 +309,9 @@ __global__ void __launch_bounds__(256) feature_match_kernel(const double* __rest
     }
     double best = DBL_MAX;
     int bidx = -1;
-    for (long long t0 = 0; t0 < nb; t0 += FM_TILE) {
-        const int rows = (int)((nb - t0) < FM_TILE ? (nb - t0) : FM_TILE);
+    const long long tb = (long long)blockIdx.y * per, te = (tb + per < nb) ? tb + per : nb;
+    for (long long t0 = tb; t0 < te; t0 += FM_TILE) {
+        const int rows = (int)((te - t0) < FM_TILE ? (te - t0) : FM_TILE);
         __syncthreads();
         for (int e = threadIdx.x; e < rows * dim; e += blockDim.x) tile[e] = B[t0 * dim + e];
         __syncthreads();
@@ -324,7 +327,22 @@ __global__ void __launch_bounds__(256) feature_match_kernel(const double* __rest
             if (s < best) { best = s; bidx = (int)(t0 + r); }
         }
     }
-    if (live) { idx_out[i] = bidx; d2_out[i] = best; }
+    if (live) { idx_out[(long long)blockIdx.y * na + i] = bidx; d2_out[(long long)blockIdx.y * na + i] = best; }
+}
+
+__global__ void feature_match_merge_kernel(const int* __restrict__ cidx, const double* __restrict__ cd2, long long na, int splits,
+                                           int* __restrict__ idx_out, double* __restrict__ d2_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    double best = DBL_MAX;
+    int bidx = -1;
+    for (int sp = 0; sp < splits; ++sp) {
+        const double d = cd2[(long long)sp * na + i];
+        const int j = cidx[(long long)sp * na + i];
+        if (j >= 0 && d < best) { best = d; bidx = j; }
+    }
+    idx_out[i] = bidx;
+    d2_out[i] = best;
 }
 
 // --------------------------------------------------------------------- RANSAC
@@ -519,12 +537,25 @@ int pcr_feature_match(pcr_ctx* ctx, const double* queries, int64_t nq, const dou
     PCR_HIP(ctx, hipMemcpyAsync(b.p, targets, sizeof(double) * dim * nt, hipMemcpyHostToDevice, ctx->stream));
     const unsigned grid = (unsigned)((nq + 255) / 256);
     const size_t lds = sizeof(double) * FM_TILE * dim;
+    // enough blocks to fill the chip: split the targets when there are few query blocks
+    int splits = (int)((4ll * ctx->cu_count + grid - 1) / grid);
+    const long long max_splits = (nt + FM_TILE - 1) / FM_TILE;
+    if (splits > max_splits) splits = (int)max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    const long long per = ((nt + splits - 1) / splits + FM_TILE - 1) / FM_TILE * FM_TILE;
+    splits = (int)((nt + per - 1) / per);
+    dev_buf ci(ctx), cd(ctx);
+    if ((rc = ci.alloc(sizeof(int) * nq * splits))) return rc;
+    if ((rc = cd.alloc(sizeof(double) * nq * splits))) return rc;
     if (dim == 33)
-        hipLaunchKernelGGL(feature_match_kernel<33>, dim3(grid), dim3(256), lds, ctx->stream, (const double*)a.as<double>(), (long long)nq,
-                           (const double*)b.as<double>(), (long long)nt, dim, di.as<int>(), dd.as<double>());
+        hipLaunchKernelGGL(feature_match_kernel<33>, dim3(grid, splits), dim3(256), lds, ctx->stream, (const double*)a.as<double>(), (long long)nq,
+                           (const double*)b.as<double>(), (long long)nt, dim, per, ci.as<int>(), cd.as<double>());
     else
-        hipLaunchKernelGGL(feature_match_kernel<0>, dim3(grid), dim3(256), lds, ctx->stream, (const double*)a.as<double>(), (long long)nq,
-                           (const double*)b.as<double>(), (long long)nt, dim, di.as<int>(), dd.as<double>());
+        hipLaunchKernelGGL(feature_match_kernel<0>, dim3(grid, splits), dim3(256), lds, ctx->stream, (const double*)a.as<double>(), (long long)nq,
+                           (const double*)b.as<double>(), (long long)nt, dim, per, ci.as<int>(), cd.as<double>());
+    hipLaunchKernelGGL(feature_match_merge_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ci.as<int>(), (const double*)cd.as<double>(),
+                       (long long)nq, splits, di.as<int>(), dd.as<double>());
     PCR_HIP(ctx, hipGetLastError());
     PCR_HIP(ctx, hipMemcpyAsync(idx_out, di.p, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
     if (d2_out) PCR_HIP(ctx, hipMemcpyAsync(d2_out, dd.p, sizeof(double) * nq, hipMemcpyDeviceToHost, ctx->stream));
