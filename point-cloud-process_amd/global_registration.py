@@ -191,8 +191,14 @@ def preprocess_point_cloud(pcd, voxel_size, ctx=None):
     """main.py:33-47 -> (pcd_down with .points/.normals, pcd_fpfh): down-sample at voxel_size, normals with radius
     2*voxel_size / 30 neighbours, FPFH with radius 5*voxel_size / 100 neighbours."""
     ctx = ctx or default_context()
-    down = PointCloud(voxel_down_sample(pcd, voxel_size, ctx=ctx))
-    cloud = DeviceCloud.upload(down.points, ctx)
+    full, own = _cloud(pcd, ctx)
+    h = C.c_void_p()
+    # mode 2 = Open3D's voxel_down_sample; the down-sampled cloud stays on the device for the normals and the descriptor
+    L.check(L.lib().pcr_voxel_filter_cloud(ctx.handle, full.handle, float(voxel_size), 2, C.c_uint64(0), C.byref(h)), ctx.handle)
+    cloud = DeviceCloud(ctx, h, L.lib().pcr_cloud_size(h))
+    if own is not None:
+        own.free()
+    down = PointCloud(cloud.download())
     down.normals = estimate_normals_hybrid(cloud, voxel_size * 2, 30, ctx=ctx)
     fpfh = compute_fpfh_feature(cloud, down.normals, voxel_size * 5, 100, ctx=ctx)
     cloud.free()
