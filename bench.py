@@ -75,6 +75,24 @@ def cpu_baseline(src, tgt, budget_s=12.0, max_iters=40):
     }
 
 
+def parity_gates(pkg, index, src, tgt):
+    """The gates SURVEY 8d asks to report next to every timing, on the bench pair itself (CPU oracle = checker only):
+    exact 1-NN of all 120k source points against scipy's tree (index mismatches away from ties, squared distances
+    bit-identical) and the composed transform after 10 ICP iterations against the CPU restatement."""
+    oracle = importlib.import_module("oracle.oracle_np")
+    s64, t64 = src.astype(np.float64), tgt.astype(np.float64)
+    idx, d2 = index.nn1(src)
+    oi, od2, margin = oracle.nn1_exact(s64, t64, workers=-1)
+    clear = margin > 1e-12
+    T_cpu, _ = oracle.icp_total(s64, t64, max_iteration=10, R_diff_thres=-1.0, t_diff_thres=-1.0)
+    sd = pkg.DeviceCloud.upload(src, index.ctx)
+    r = pkg.icp_device(sd, index, np.eye(4), mode="total", max_iter=10, r_thres=-1.0, t_thres=-1.0, max_d2=MAX_D2, min_iter=10)
+    sd.free()
+    return {"nn_index_mismatch_away_from_ties": int((idx[clear] != oi[clear]).sum()), "nn_ties_excluded": int((~clear).sum()),
+            "nn_d2_bit_identical": bool(np.array_equal(d2, od2)),
+            "Rt_frobenius_vs_cpu_after_10_iters": float(np.linalg.norm(r["T_total"] - T_cpu)), "tolerance": 1e-4}
+
+
 def run_icp_steps(pkg, index, src_host, steps, ctx):
     """Exactly `steps` ICP iterations (thresholds off), device-resident inputs.  Returns dict."""
     out = {"iters": 0, "device_ms": 0.0, "nn_kernel_ms": 0.0, "nn_launches": 0}
@@ -292,6 +310,8 @@ def main():
             line["concurrent_pairs"] = concurrent_leg(pkg, dev_id, src, tgt, a.in_flight, min(a.steps, 100))
         if world == 1 and not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(src, tgt)
+            if a.nn == "grid" and a.points <= 200_000:
+                line["parity"] = parity_gates(pkg, index, src, tgt)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
