@@ -13,6 +13,7 @@ from . import synthetic  # noqa: F401
 from .device import Context, DeviceCloud, TargetIndex, default_context, icp_device  # noqa: F401
 from .registration import (  # noqa: F401
     ICP,
+    coarse_to_fine_icp,
     KDTreeFlann,
     PointCloud,
     copysign,

@@ -20,7 +20,7 @@ __all__ = [
     "PointCloud",
     "KDTreeFlann",
     "icp_point2point",
-    "ICP",
+    "ICP", "coarse_to_fine_icp",
     "find_associations",
     "procrustes_transformation",
     "rotmat2quaternion",
@@ -198,6 +198,39 @@ def procrustes_transformation(A, B):
     cost = C.c_double()
     L.check(L.lib().pcr_procrustes(L.dptr(A), L.dptr(B), A.shape[1], L.dptr(R), L.dptr(t), C.byref(cost)))
     return R.reshape(3, 3), t.reshape(3, 1), cost.value
+
+
+def coarse_to_fine_icp(src_cloud, tgt_cloud, leaves=(1.0, 0.4, 0.0), *, init=None, max_iteration=30, R_diff_thres=1e-5,
+                       t_diff_thres=1e-5, dist_thres=5.0, ctx=None):
+    """BASELINE config 5's refinement: ICP (icp_template.py:128-200 semantics, composed transform) on voxel-filtered copies
+    of both clouds, coarsest leaf first, each level starting from the previous level's transform; leaf 0 = full
+    resolution.  Everything stays on the device between levels.  Returns (homo_mat_total, [log per level])."""
+    from .voxel_filter import voxel_filter_device
+
+    ctx = ctx or default_context()
+    T = np.eye(4) if init is None else np.array(init, dtype=np.float64).reshape(4, 4)
+    src_full = DeviceCloud.upload(points_of(src_cloud), ctx)
+    tgt_full = DeviceCloud.upload(points_of(tgt_cloud), ctx)
+    logs = []
+    try:
+        for leaf in leaves:
+            s = voxel_filter_device(src_full, leaf) if leaf > 0 else DeviceCloud.upload(src_full.download(), ctx)
+            t = voxel_filter_device(tgt_full, leaf) if leaf > 0 else tgt_full
+            index = TargetIndex(t, ctx=ctx)
+            try:
+                res = icp_device(s, index, T, mode="total", max_iter=max_iteration, r_thres=R_diff_thres, t_thres=t_diff_thres,
+                                 max_d2=dist_thres, r_metric="geodesic")
+            finally:
+                index.free()
+                s.free()
+                if t is not tgt_full:
+                    t.free()
+            T = res["T"]
+            logs.append({"leaf": leaf, "iters": res["iters"], "n_assoc": res["n_assoc"], "mean_d2": res["mean_d2"]})
+    finally:
+        src_full.free()
+        tgt_full.free()
+    return T, logs
 
 
 def copysign(v, s):

@@ -59,4 +59,13 @@ kp, lam, counts = pcp.iss_keypoints(cloud, radius=0.6, non_max_radius=0.6, iss_c
 out["C5_iss_1M_points_s"] = time.perf_counter() - t0
 out["C5_mean_neighbours"] = float(counts.mean())
 out["C5_keypoints"] = len(kp)
+# C5 continued: coarse-to-fine ICP of two 1M-point scans of the same world (8 frames each, second set shifted)
+T_off = syn.rigid_transform((0.05, 0.0, 1.0), np.deg2rad(3.0), (0.8, -0.4, 0.02))
+world2 = (world - T_off[:3, 3]) @ T_off[:3, :3]          # world = T_off * world2
+world2 = world2 + np.random.default_rng(7).normal(0, 0.01, world2.shape)
+t0 = time.perf_counter()
+Tc, logs = pcp.coarse_to_fine_icp(world2, world, leaves=(2.0, 0.5, 0.0), max_iteration=30)
+out["C5_coarse_to_fine_icp_1M_s"] = time.perf_counter() - t0
+out["C5_icp_levels"] = logs
+out["C5_icp_error_vs_truth"] = float(np.abs(Tc - T_off).max())
 print(json.dumps(out, indent=1))

@@ -161,3 +161,14 @@ def test_kdtreeflann_radius_search(pcp, oracle, syn):
     assert k == len(ref) and set(idx) == set(ref.tolist()) and np.all(np.diff(d2) >= 0)
     k2, idx2, _ = tree.search_hybrid_vector_3d(pts[123] + 0.01, 1.5, 10)
     assert k2 == min(10, k) and idx2 == idx[:k2]
+
+
+def test_coarse_to_fine_icp_config5(pcp, syn):
+    """BASELINE config 5's refinement: down-sampled levels first, each starting from the previous transform; a 6 degree /
+    1.2 m offset that full-resolution ICP alone resolves more slowly is brought inside the evaluator's success gate."""
+    src, tgt, T_true = syn.perturbed_pair(120000, seed=5, angle_deg=6.0, t=(1.2, -0.6, 0.05))
+    T, logs = pcp.coarse_to_fine_icp(src, tgt, leaves=(1.0, 0.4, 0.0), max_iteration=40)
+    assert [l["leaf"] for l in logs] == [1.0, 0.4, 0.0]
+    ok, rte, rre = pcp.is_registration_successful(T, T_true)
+    assert ok and rte < 0.5 and rre < 1.0, (rte, rre, logs)
+    assert logs[-1]["n_assoc"] > 100000
