@@ -887,7 +887,8 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;
-    const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
+    static const int hard_mult = getenv("PCR_HARD_MULT") ? atoi(getenv("PCR_HARD_MULT")) : 8;
+    const int g3 = (int)(want < (long long)hard_mult * ctx->cu_count ? (want < 1 ? 1 : want) : (long long)hard_mult * ctx->cu_count);
     hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, stream, idx->view, (const work_item*)sc->hard_list,
                        (const unsigned int*)sc->hard_count, (long long)nq, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug);
     PCR_HIP(ctx, hipGetLastError());
