@@ -195,13 +195,13 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
             __syncthreads();
             for (int bq = tid; bq < nblk; bq += 256) {
                 int iz = (int)((float)bq * binv01);
-                iz -= (iz * nb01 > bq);
-                iz += ((iz + 1) * nb01 <= bq);
-                const int rem = bq - iz * nb01;
+                iz -= (__mul24(iz, nb01) > bq);  // 24-bit multiplies: full rate (v_mul_lo_u32 is a quarter-rate op)
+                iz += (__mul24(iz + 1, nb01) <= bq);
+                const int rem = bq - __mul24(iz, nb01);
                 int iy = (int)((float)rem * binv0);
-                iy -= (iy * nb0 > rem);
-                iy += ((iy + 1) * nb0 <= rem);
-                const int ix = rem - iy * nb0;
+                iy -= (__mul24(iy, nb0) > rem);
+                iy += (__mul24(iy + 1, nb0) <= rem);
+                const int ix = rem - __mul24(iy, nb0);
                 const int BX = bx0 + ix, BY = by0 + iy, BZ = bz0 + iz;
                 if (BX < 0 || BY < 0 || BZ < 0 || BX > blim || BY > blim || BZ > blim) continue;
                 pcr_block_slot e;
@@ -219,7 +219,7 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
                     }
                     run += cn;
                     if (X >= 0 && Y >= 0 && Z >= 0 && X < d0 && Y < d1 && Z < sm.dims[2]) {
-                        const int c = X + Y * d0 + Z * d01;
+                        const int c = X + __mul24(Y, d0) + __mul24(Z, d01);
                         sm.c_start[c] = cs;
                         sm.c_off[c] = cn;
                     }
