@@ -9,7 +9,8 @@
   the last entry (result_set.py:37-50); unfilled slots read (1e10, 0) (result_set.py:19-22);
 * radius: ``dist > radius`` is rejected, i.e. the ball is closed (result_set.py:80).
 
-The bookkeeping is a bisect over a plain list of keys rather than the reference's shifting loop.
+Both containers share one base (counters, report formatting); the k-NN set keeps a sorted key list and
+places a new entry with ``bisect`` instead of the reference's shifting loop.
 """
 from __future__ import annotations
 
@@ -22,8 +23,7 @@ class DistIndex:
     __slots__ = ("distance", "index")
 
     def __init__(self, distance, index):
-        self.distance = distance
-        self.index = index
+        self.distance, self.index = distance, index
 
     def __lt__(self, other):
         return self.distance < other.distance
@@ -32,17 +32,48 @@ class DistIndex:
         return f"DistIndex({self.distance!r}, {self.index!r})"
 
 
-class KNNResultSet:
-    def __init__(self, capacity):
-        self.capacity = capacity
+class _Collector:
+    """What both result sets have in common: the two counters and the text report."""
+
+    def __init__(self):
         self.count = 0
-        self.worst_dist = _UNSET_DISTANCE
         self.comparison_counter = 0
-        self._keys = []  # distances of the filled entries, ascending
-        self.dist_index_list = [DistIndex(_UNSET_DISTANCE, 0) for _ in range(capacity)]
+        self.dist_index_list = []
 
     def size(self):
         return self.count
+
+    def _report(self, tail):
+        return "\n".join(["%d - %.2f" % (e.index, e.distance) for e in self.dist_index_list] + [tail])
+
+
+class RadiusNNResultSet(_Collector):
+    def __init__(self, radius):
+        super().__init__()
+        self.radius = self.worst_dist = radius
+
+    def worstDist(self):
+        return self.radius
+
+    def add_point(self, dist, index):
+        self.comparison_counter += 1
+        if dist <= self.radius or dist != dist:  # closed ball; the reference's `dist > radius` test also lets NaN through
+            self.count += 1
+            self.dist_index_list.append(DistIndex(dist, index))
+
+    def __str__(self):
+        self.dist_index_list.sort()
+        return self._report("In total %d neighbors within %f.\nThere are %d comparison operations."
+                            % (self.count, self.radius, self.comparison_counter))
+
+
+class KNNResultSet(_Collector):
+    def __init__(self, capacity):
+        super().__init__()
+        self.capacity = capacity
+        self.worst_dist = _UNSET_DISTANCE
+        self.dist_index_list = [DistIndex(_UNSET_DISTANCE, 0) for _ in range(capacity)]
+        self._keys = []  # distances of the filled entries, ascending
 
     def full(self):
         return self.count == self.capacity
@@ -52,49 +83,18 @@ class KNNResultSet:
 
     def add_point(self, dist, index):
         self.comparison_counter += 1
-        if dist > self.worst_dist or self.capacity == 0:
+        if self.capacity == 0 or dist > self.worst_dist:
             return
-        filled = self.dist_index_list[: self.count]
-        if self.count == self.capacity:
-            # the incoming entry takes the place of the current last one, then settles among the rest
-            filled.pop()
-            self._keys.pop()
+        if self.full():
+            del self._keys[-1]  # the newcomer displaces the current last entry, then settles among the rest
         else:
             self.count += 1
         at = bisect_right(self._keys, dist)
         self._keys.insert(at, dist)
-        filled.insert(at, DistIndex(dist, index))
-        self.dist_index_list[: self.count] = filled
-        self.worst_dist = self.dist_index_list[self.capacity - 1].distance
+        live = self.dist_index_list[: len(self._keys) - 1]
+        live.insert(at, DistIndex(dist, index))
+        self.dist_index_list[: len(live)] = live
+        self.worst_dist = self.dist_index_list[-1].distance
 
     def __str__(self):
-        rows = ["%d - %.2f" % (e.index, e.distance) for e in self.dist_index_list]
-        rows.append("In total %d comparison operations." % self.comparison_counter)
-        return "\n".join(rows)
-
-
-class RadiusNNResultSet:
-    def __init__(self, radius):
-        self.radius = radius
-        self.worst_dist = radius
-        self.count = 0
-        self.comparison_counter = 0
-        self.dist_index_list = []
-
-    def size(self):
-        return self.count
-
-    def worstDist(self):
-        return self.radius
-
-    def add_point(self, dist, index):
-        self.comparison_counter += 1
-        if not dist > self.radius:
-            self.dist_index_list.append(DistIndex(dist, index))
-            self.count += 1
-
-    def __str__(self):
-        self.dist_index_list.sort()
-        rows = ["%d - %.2f" % (e.index, e.distance) for e in self.dist_index_list]
-        rows.append("In total %d neighbors within %f.\nThere are %d comparison operations." % (self.count, self.radius, self.comparison_counter))
-        return "\n".join(rows)
+        return self._report("In total %d comparison operations." % self.comparison_counter)
