@@ -27,7 +27,7 @@ constexpr int BR_QPB = BR_NT * 16 * BR_WAVES;  // queries per block = 256
 constexpr int BR_PAD = 8;         // never-winning padding tiles behind the last real one (unconditional prefetch)
 
 __global__ void brute_prep_kernel(const pcr_pt* __restrict__ pts, long long n, long long n_tiles, double ox, double oy, double oz,
-                                  double* __restrict__ mfma_a) {
+                                  double bias, double* __restrict__ mfma_a) {
     long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (n_tiles + BR_PAD) * 64) return;
     long long t = g >> 6;
@@ -38,7 +38,10 @@ __global__ void brute_prep_kernel(const pcr_pt* __restrict__ pts, long long n, l
     if (j < n) {
         pcr_pt p = pts[j];
         double bx = p.x - ox, by = p.y - oy, bz = p.z - oz;
-        v = (k == 0) ? -2.0 * bx : (k == 1) ? -2.0 * by : (k == 2) ? -2.0 * bz : ((bx * bx + by * by) + bz * bz);
+        // `bias` keeps every contraction result positive (the expanded form can come out a few ulps below zero for a
+        // coincident pair): the epilogue packs the tile index into the low mantissa bits and relies on the ordering of
+        // positive doubles; a uniform offset does not change the ranking and the reported d^2 comes from the exact recheck
+        v = (k == 0) ? -2.0 * bx : (k == 1) ? -2.0 * by : (k == 2) ? -2.0 * bz : (((bx * bx + by * by) + bz * bz) + bias);
     } else {
         v = (k == 3) ? 1e300 : 0.0;  // padding rows can never win
     }
@@ -61,6 +64,14 @@ struct brute_cand {  // per (target split, query): best candidate of that split
 // plain v_min_f64: this file is compiled with -fno-honor-nans so fmin() does not canonicalise its inputs
 // (an inline-asm v_min_f64 is not an option here: hipcc inserts no MFMA->VALU wait states for asm operands).
 __device__ static inline double bvmin(double a, double b) { return fmin(a, b); }
+
+// The running minimum carries the tile index in the low 16 mantissa bits (values are positive, so the ordering of the
+// doubles is the ordering of (value rounded down to 36 mantissa bits, tile)): one v_and_or_b32 + one v_min_f64 per row
+// minimum instead of compare + three selects.  2^-36 relative is far below the ~1e-9 relative noise of the expanded form.
+constexpr unsigned int BR_CODE_MASK = 0xffffu;
+__device__ static inline double pack_code(double m, unsigned int code) {
+    return __hiloint2double(__double2hiint(m), (int)(((unsigned int)__double2loint(m) & ~BR_CODE_MASK) | code));
+}
 
 __device__ static inline double dist2_pt(double ax, double ay, double az, const pcr_pt& b) {
     double dx = ax - b.x, dy = ay - b.y, dz = az - b.z;
@@ -130,12 +141,11 @@ brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tg
                 v4f64 cur[BR_NT];
 #pragma unroll
                 for (int tt = 0; tt < BR_NT; ++tt) cur[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[i], bq[tt], zero, 0, 0, 0);
+                const unsigned int code = (unsigned int)(tb + i - 1 - t0) & BR_CODE_MASK;  // tile of the accumulators being folded
 #pragma unroll
                 for (int tt = 0; tt < BR_NT; ++tt) {
                     const double m = bvmin(bvmin(acc[tt][0], acc[tt][1]), bvmin(acc[tt][2], acc[tt][3]));
-                    const bool lt = m < best[tt];
-                    best[tt] = lt ? m : best[tt];
-                    btile[tt] = lt ? (int)(tb + i - 1) : btile[tt];
+                    best[tt] = bvmin(best[tt], pack_code(m, code));
                 }
 #pragma unroll
                 for (int tt = 0; tt < BR_NT; ++tt) acc[tt] = cur[tt];
@@ -145,11 +155,10 @@ brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tg
         }
         const long long t_last = t0 + ((t1 - t0 + BR_PF - 1) / BR_PF) * BR_PF - 1;
 #pragma unroll
-        for (int tt = 0; tt < BR_NT; ++tt) {  // epilogue of the last tile
+        for (int tt = 0; tt < BR_NT; ++tt) {  // epilogue of the last tile, then unpack the winning tile
             const double m = bvmin(bvmin(acc[tt][0], acc[tt][1]), bvmin(acc[tt][2], acc[tt][3]));
-            const bool lt = m < best[tt];
-            best[tt] = lt ? m : best[tt];
-            btile[tt] = lt ? (int)t_last : btile[tt];
+            best[tt] = bvmin(best[tt], pack_code(m, (unsigned int)(t_last - t0) & BR_CODE_MASK));
+            btile[tt] = best[tt] < 1e299 ? (int)(t0 + ((unsigned int)__double2loint(best[tt]) & BR_CODE_MASK)) : -1;
         }
     }
     // exact re-evaluation of each lane's 4 candidate rows, then merge the 4 row groups of a query
@@ -286,8 +295,11 @@ int pcr_brute_build(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_index* idx) {
     // row order (record id == position), whatever order the cloud currently has on the device
     hipLaunchKernelGGL(brute_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)tgt->d, n, idx->plain);
     const long long threads = (idx->n_tiles + BR_PAD) * 64;
+    double r2 = 0.0;
+    for (int k = 0; k < 3; ++k) r2 += 0.25 * (idx->hi[k] - idx->lo[k]) * (idx->hi[k] - idx->lo[k]);
+    const double bias = (r2 > 0 ? r2 : 1.0) * 3.6379788070917130e-12;  // R^2 * 2^-38: above the cancellation noise of a coincident pair
     hipLaunchKernelGGL(brute_prep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)idx->plain, n,
-                       (long long)idx->n_tiles, idx->view.origin[0], idx->view.origin[1], idx->view.origin[2], idx->mfma_a);
+                       (long long)idx->n_tiles, idx->view.origin[0], idx->view.origin[1], idx->view.origin[2], bias, idx->mfma_a);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
@@ -306,6 +318,8 @@ static int brute_splits(pcr_ctx* ctx, long long nq, long long n_tiles) {
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     if (s > n_tiles) s = n_tiles;
+    const long long min_s = (n_tiles + 65535) / 65536;  // the tile index inside a split must fit the 16 packed bits
+    if (s < min_s) s = min_s;
     return (int)s;
 }
 
