@@ -256,6 +256,10 @@ PCR_API int pcr_timer_stop_ms(pcr_ctx* ctx, double* ms_out);
 /* diagnostics: per-block {cycles, work} stamps of the last grid search stage kernels (PCR_DEBUG_STAMPS=1) */
 PCR_API int pcr_debug_read(pcr_ctx* ctx, uint64_t* out, int64_t n_words);
 PCR_API int pcr_profile_enable(pcr_ctx* ctx, int on);
+/* diagnostics of the LAST correspondence search on this context (Registration/main.py:116-121 is the step they describe):
+ * out[0] = queries the brute-force MFMA sweep could not prove and re-did with the exact direct-form sweep,
+ * out[1..3] reserved (0).  Exactness never depends on these numbers; tests use them to see the fallback fire.   */
+PCR_API int pcr_search_stats(pcr_ctx* ctx, int64_t out[4]);
 PCR_API int pcr_profile_read(pcr_ctx* ctx, double ms_out[4], int* passes_out);
 
 #ifdef __cplusplus

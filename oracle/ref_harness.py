@@ -185,15 +185,17 @@ def gen_nn_api(syn):
                 D = np.zeros((nq, k))
                 I = np.zeros((nq, k), dtype=np.int64)
                 C = np.zeros(nq, dtype=np.int64)
+                RET = np.zeros(nq, dtype=np.int64)
                 for qi, q in enumerate(queries):
                     r = rs.KNNResultSet(capacity=k)
-                    fn(root, db, r, q)
+                    RET[qi] = int(bool(fn(root, db, r, q)))  # octree.py:187,212 "ball inside octant"; kdtree.py: always False
                     D[qi] = [x.distance for x in r.dist_index_list]
                     I[qi] = [x.index for x in r.dist_index_list]
                     C[qi] = r.comparison_counter
                 out[f"{name}_{tree}_knn{k}_dist"] = D
                 out[f"{name}_{tree}_knn{k}_idx"] = I
                 out[f"{name}_{tree}_knn{k}_cmp"] = C
+                out[f"{name}_{tree}_knn{k}_ret"] = RET
         for rad in (0.5, 1.0) if name != "rand64" else (0.25, 0.5):
             for tree, fn, root in (
                 ("kd", kd.kdtree_radius_search, kroot),
@@ -202,7 +204,8 @@ def gen_nn_api(syn):
             ):
                 for qi, q in enumerate(queries):
                     r = rs.RadiusNNResultSet(radius=rad)
-                    fn(root, db, r, q)
+                    ret = fn(root, db, r, q)  # octree.py:235,259,281,306
+                    out[f"{name}_{tree}_rad{rad}_q{qi}_ret"] = np.array([int(bool(ret))], dtype=np.int64)
                     lst = sorted(r.dist_index_list)
                     out[f"{name}_{tree}_rad{rad}_q{qi}_dist"] = np.array([x.distance for x in lst])
                     out[f"{name}_{tree}_rad{rad}_q{qi}_idx"] = np.array([x.index for x in lst], dtype=np.int64)
@@ -261,6 +264,7 @@ def gen_icp(syn, big=False):
         return real_svd(*a, **k)
 
     def run(tag, src, tgt, T0):
+        nonlocal out
         S = _PointCloud(src)
         Tg = _PointCloud(tgt)
         svd_calls[0] = 0
@@ -305,11 +309,16 @@ def gen_icp(syn, big=False):
     s64 = src[:1500].astype(np.float64) + rng.normal(0, 1e-3, (1500, 3))
     t64 = tgt[:2500].astype(np.float64) + rng.normal(0, 1e-3, (2500, 3))
     run("f64_1500", s64, t64, np.eye(4))
-    if big:
-        src, tgt, Tt = syn.perturbed_pair(20000, seed=6)
-        run("kitti20000_id", src, tgt, np.eye(4))
     out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(GOLD, "icp_compat.npz"), **out)
+    if big:
+        # SURVEY 8c G3 at N = 20 000 (the largest size the literal N x N centring can execute: ~40 s, ~10 GB);
+        # kept in its own file so the small cases can be regenerated without it
+        out, n0 = {}, len(cases)
+        src, tgt, Tt = syn.perturbed_pair(20000, seed=6)
+        run("kitti20000_id", src, tgt, np.eye(4))
+        out["cases"] = np.array(cases[n0:])
+        np.savez_compressed(os.path.join(GOLD, "icp_compat_big.npz"), **out)
 
     # G4 pose utils
     pose = {}
@@ -451,6 +460,35 @@ def gen_dbscan(syn):
     np.savez_compressed(os.path.join(GOLD, "dbscan.npz"), **out)
 
 
+# --------------------------------------------------------------------------
+# G9: the three .bin readers (Registration/main.py:10-17, icp_template.py:11-17,
+#     Kdtree_Octree/lesson2/benchmark.py:16-27) on seeded synthetic files
+# --------------------------------------------------------------------------
+def gen_readers(syn):
+    import tempfile
+
+    install_stubs()
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path.insert(0, os.path.join(REF, "Kdtree_Octree", "lesson2"))
+    main = import_ref("Registration", "main")
+    tmpl = import_ref("Registration", "icp_template")
+    bench = import_ref(os.path.join("Kdtree_Octree", "lesson2"), "benchmark")
+    rng = np.random.default_rng(91)
+    rec6 = rng.normal(0, 20, (257, 6)).astype(np.float32)   # x,y,z,nx,ny,nz records (registration_dataset)
+    rec4 = rng.normal(0, 20, (301, 4)).astype(np.float32)   # x,y,z,intensity records (KITTI velodyne)
+    d = tempfile.mkdtemp()
+    f6, f4 = os.path.join(d, "six.bin"), os.path.join(d, "four.bin")
+    rec6.tofile(f6)
+    rec4.tofile(f4)
+    out = {"rec6": rec6, "rec4": rec4}
+    out["read_bin_velodyne"] = main.read_bin_velodyne(f6)
+    out["read_oxford_bin"] = tmpl.read_oxford_bin(f6)
+    out["read_velodyne_bin"] = bench.read_velodyne_bin(f4)
+    for k in ("read_bin_velodyne", "read_oxford_bin", "read_velodyne_bin"):
+        print("reader", k, out[k].shape, out[k].dtype)
+    np.savez_compressed(os.path.join(GOLD, "readers.npz"), **out)
+
+
 def ev_tq(T):
     """t, q (w first) of a pose for the result files (same convention as main.py:170-174, via scipy)."""
     from scipy.spatial.transform import Rotation
@@ -482,6 +520,8 @@ def main():
         gen_pca(syn)
     if a.only in ("", "dbscan"):
         gen_dbscan(syn)
+    if a.only in ("", "readers"):
+        gen_readers(syn)
 
 
 if __name__ == "__main__":

@@ -128,6 +128,17 @@ int pcr_profile_read(pcr_ctx* c, double ms_out[4], int* passes_out) {
     return PCR_OK;
 }
 
+int pcr_search_stats(pcr_ctx* c, int64_t out[4]) {
+    if (!c || !out) return PCR_E_INVALID;
+    hipSetDevice(c->device);
+    unsigned int fb = 0;
+    int rc = pcr_brute_last_fallback(c, &fb);
+    if (rc) return rc;
+    out[0] = fb;
+    out[1] = out[2] = out[3] = 0;
+    return PCR_OK;
+}
+
 int pcr_timer_start(pcr_ctx* c) {
     if (!c) return PCR_E_INVALID;
     PCR_HIP(c, hipEventRecord(c->ev2, c->stream));

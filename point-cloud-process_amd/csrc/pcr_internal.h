@@ -78,6 +78,7 @@ struct pcr_index {
     double* mfma_a = nullptr;   // [n_tiles][64]
     pcr_pt* plain = nullptr;    // targets in original order, centred copy not needed (exact recheck uses these)
     int64_t n_tiles = 0;
+    double brute_rt = 0, brute_bias = 0;  // half diagonal of the target box; offset that keeps the contraction positive
 };
 
 struct pcr_ctx {
@@ -156,6 +157,7 @@ PCR_HIDDEN int pcr_brute_build(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_index* id
 PCR_HIDDEN void pcr_brute_free(pcr_ctx* ctx, pcr_index* idx);
 PCR_HIDDEN int pcr_brute_nn1(pcr_ctx* ctx, const pcr_index* idx, const pcr_pt* q, int64_t nq, const pcr_xform* x,
                              double max_d2, int32_t* d_idx, double* d_d2);
+PCR_HIDDEN int pcr_brute_last_fallback(pcr_ctx* ctx, unsigned int* out);
 PCR_HIDDEN int pcr_brute_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, const pcr_xform* x,
                                   double max_d2, int write_back, double* d_moments);
 

@@ -53,6 +53,12 @@ class Context:
         L.check(L.lib().pcr_profile_read(self.handle, L.dptr(ms), C.byref(n)), self.handle)
         return ms, n.value
 
+    def search_stats(self):
+        """Diagnostics of the last correspondence search: {"brute_fallback": queries re-done by the exact sweep}."""
+        out = np.zeros(4, dtype=np.int64)
+        L.check(L.lib().pcr_search_stats(self.handle, L.lptr(out)), self.handle)
+        return {"brute_fallback": int(out[0])}
+
     def close(self):
         if self._h:
             L.lib().pcr_ctx_destroy(self._h)

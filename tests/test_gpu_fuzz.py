@@ -1,5 +1,5 @@
-"""GPU: randomised parity sweep of the exact 1-NN grid path (tile directory through the block tables, grouped filter,
-hard stage) and of the fused ICP moments against the CPU oracle -- shapes, densities, cell sizes and offsets the fixed
+"""GPU: randomised parity sweep of BOTH exact 1-NN paths -- grid (tile directory through the block tables, grouped filter,
+hard stage) and brute force (f64 MFMA sweep, group argmin, proven-or-fallback) -- and of the fused ICP moments against the CPU oracle -- shapes, densities, cell sizes and offsets the fixed
 tests do not cover.  Every case is seeded; distances must be bit-identical, indices equal outside exact ties."""
 import numpy as np
 import pytest
@@ -42,8 +42,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("nn", ["grid", "brute"])
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_nn1_fuzz(pcp, oracle, case):
+def test_nn1_fuzz(pcp, oracle, case, nn):
     kind, n_t, n_q, cell, off, spread = CASES[case]
     rng = np.random.default_rng(1000 + case)
     tgt = _cloud(rng, kind, n_t) + off
@@ -54,10 +55,10 @@ def test_nn1_fuzz(pcp, oracle, case):
     if n_q >= 100:
         q[:5] += 500.0          # far outside the grid
         q[5:10] = tgt[:5] if n_t >= 5 else q[5:10]   # exact hits (distance 0)
-    index = pcp.TargetIndex(tgt, kind="grid", cell=cell)
+    index = pcp.TargetIndex(tgt, kind=nn, cell=cell)
     idx, d2 = index.nn1(q)
     oi, od2, margin = oracle.nn1_exact(q, tgt)
-    assert np.array_equal(d2, od2), (kind, n_t, cell)
+    assert np.array_equal(d2, od2), (kind, n_t, cell, nn)
     clear = margin > TIE_MARGIN
     assert np.array_equal(idx[clear], oi[clear])
     # on exact ties the lowest index wins

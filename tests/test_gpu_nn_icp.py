@@ -185,16 +185,53 @@ def test_nn1_far_from_origin_and_odd_sizes(pcp, oracle, syn):
         assert np.array_equal(i2, np.arange(n)) and (dd == 0).all()
 
 
-def test_nn1_dense_volume_and_clustered_duplicates(pcp, oracle):
+@pytest.mark.parametrize("kind", ["grid", "brute"])
+def test_nn1_dense_volume_and_clustered_duplicates(pcp, oracle, kind):
     rng = np.random.default_rng(9)
     tgt = rng.uniform(0, 2.0, (40000, 3))
     tgt[5000:5200] = tgt[100]  # 200 exact duplicates of one point: ties must resolve to the lowest index
     q = rng.uniform(-0.1, 2.1, (5000, 3))
     q[:50] = tgt[100] + rng.normal(0, 1e-4, (50, 3))
-    idx, d2 = pcp.TargetIndex(tgt, kind="grid").nn1(q)
+    index = pcp.TargetIndex(tgt, kind=kind)
+    idx, d2 = index.nn1(q)
     bi, bd2 = oracle.nn1_bruteforce(q, tgt)
     assert np.array_equal(d2, bd2)
     assert np.array_equal(idx, bi)  # np.argmin also returns the first (lowest) index on ties
+    if kind == "brute":
+        # the 50 queries next to the 200 duplicates cannot be proven by the packed argmin: they took the exact sweep
+        assert index.ctx.search_stats()["brute_fallback"] >= 50
+
+
+def test_brute_two_distant_dense_clusters(pcp, oracle):
+    """The case the round-1 brute-force kernel got wrong: two dense 0.3 m clusters 2 km apart.
+    About the box centre |a'|^2 ~ 1e6 m^2 while neighbour d^2 ~ 1e-5 m^2; ranking d^2 - |a'|^2 at 2^-36 relative
+    mis-ranked 14 of 20 000 queries.  With |a'|^2 in the MFMA C operand the packed value is d^2 + bias, the rigorous
+    band sends what cannot be proven to the exact sweep, and every index must equal scipy's (ties excluded)."""
+    rng = np.random.default_rng(77)
+    c = np.array([[0.0, 0.0, 0.0], [2000.0, 0.0, 0.0]])
+    tgt = c[rng.integers(0, 2, 60000)] + rng.uniform(-0.15, 0.15, (60000, 3))
+    q = tgt[rng.integers(0, 60000, 20000)] + rng.normal(0, 0.003, (20000, 3))
+    index = pcp.TargetIndex(tgt, kind="brute")
+    idx, d2 = index.nn1(q)
+    fb = index.ctx.search_stats()["brute_fallback"]
+    oi, od2, margin = oracle.nn1_exact(q, tgt)
+    assert np.array_equal(d2, od2)
+    clear = margin > TIE_MARGIN
+    assert np.array_equal(idx[clear], oi[clear])
+    assert fb < 2000, fb   # the band is ~1e-8 m^2 here: the fallback is the exception, not the path
+    # same through the fused ICP pass (gate = the reference's 5 m^2, main.py:103)
+    m, o, s = index.moments(q, np.eye(4), max_d2=5.0)
+    assert int(round(m[0])) == int((od2 < 5.0).sum())
+    assert abs(s - od2[od2 < 5.0].sum()) <= 1e-9 * max(1.0, od2.sum())
+
+
+def test_brute_kitti_scan_proves_itself(pcp, syn):
+    """On a KITTI-shaped pair the sweep's own bound proves (almost) every query: the exact fallback stays idle, so the
+    measured sweep time is the production time."""
+    src, tgt, _ = syn.perturbed_pair(120000, seed=0)
+    index = pcp.TargetIndex(tgt, kind="brute")
+    index.nn1(src)
+    assert index.ctx.search_stats()["brute_fallback"] <= 8
 
 
 def test_icp_is_bitwise_reproducible(pcp, syn):
