@@ -58,6 +58,7 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
         delete c;
         return PCR_E_NOMEM;
     }
+    if (hipHostMalloc(&c->h_state, 8192, hipHostMallocDefault) != hipSuccess) { delete c; return PCR_E_NOMEM; }
     if (hipMalloc((void**)&c->d_counters, PCR_COUNTER_BYTES) != hipSuccess) { delete c; return PCR_E_NOMEM; }
     hipMemsetAsync(c->d_counters, 0, PCR_COUNTER_BYTES, c->stream);
     if (getenv("PCR_DEBUG_STAMPS")) {
@@ -77,6 +78,7 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     if (c->d_counters) hipFree(c->d_counters);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_slabs) hipHostFree(c->h_slabs);
+    if (c->h_state) hipHostFree(c->h_state);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipEventDestroy(c->ev2);
@@ -188,6 +190,7 @@ int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out) {
     }
     if (best >= 0) {
         *out = ctx->free_list[best].p;
+        ctx->live.push_back(ctx->free_list[best]);  // remember the block's true capacity, not the request
         ctx->free_list.erase(ctx->free_list.begin() + best);
         return PCR_OK;
     }
@@ -208,6 +211,7 @@ int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out) {
     }
     *out = (char*)ctx->arenas.back() + ctx->arena_used;
     ctx->arena_used += bytes;
+    ctx->live.push_back({*out, bytes});
     return PCR_OK;
 }
 
@@ -215,7 +219,17 @@ void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes) {
     if (!p) return;
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
-    // frees are stream-ordered with later allocations because every user of the block runs on ctx->stream
+    // the block goes back with its true capacity (a larger recycled block would otherwise lose its tail for good)
+    for (int i = (int)ctx->live.size() - 1; i >= 0; --i) {
+        if (ctx->live[i].p == p) {
+            bytes = ctx->live[i].sz;
+            ctx->live[i] = ctx->live.back();
+            ctx->live.pop_back();
+            break;
+        }
+    }
+    // Frees are stream-ordered with later allocations: every user of a block runs on ctx->stream, or on a lane stream
+    // that the ICP pass synchronises before it frees (pcr_grid_icp_pass).
     ctx->free_list.push_back({p, bytes});
 }
 

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "pcr_grid_dev.h"
+#include "pcr_icp_step.h"
 
 constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
 constexpr int T_MAXC = 512;                 // cells in a tile box (1024: more sparse tiles stay at a fine level and leave their queries unresolved; 256 and below: boxes at the coarser level overflow the candidate cap)
@@ -100,8 +101,12 @@ struct tile_smem {
 __global__ void __launch_bounds__(256)
 grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
                  int gated, int xcd_remap, unsigned int pcap, int maxc, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
-                 unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg) {
+                 unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg, const pcr_icp_dev_state* __restrict__ st) {
     __shared__ tile_smem sm;
+    if (st) {  // device-resident ICP loop: this pass applies the increment the previous pass solved; no-op behind a stop
+        if (st->stop) return;
+        x = st->x;
+    }
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_ph[5] = {0, 0, 0, 0, 0};
 #define PH_STAMP(i) do { if (dbg) t_ph[i] = __builtin_amdgcn_s_memtime() - t_start; } while (0)
@@ -577,8 +582,10 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
 // (115 VGPRs -> 4 waves per SIMD; forcing 5, 6 or 8 with amdgpu_waves_per_eu spills and measured 31, 39, 50 us against 29)
 __global__ void __launch_bounds__(256)
 grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ count_p, long long nq, double max_d2, int gated,
-                 unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, unsigned long long* __restrict__ dbg) {
+                 unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, unsigned long long* __restrict__ dbg,
+                 const pcr_icp_dev_state* __restrict__ st) {
     __shared__ hard_lds s_lds[4];
+    if (st && st->stop) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     hard_lds* L = &s_lds[wave];
     // exclusive prefix of the sub-list lengths (lanes 0..H_NLIST-1 hold one list each)
@@ -744,8 +751,10 @@ __global__ void grid_finalize_nn1_kernel(pcr_grid_view gv, const pcr_pt* __restr
 __global__ void __launch_bounds__(256)
 grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long nq, pcr_xform x, int apply_x,
                        const unsigned int* __restrict__ res_pos, double max_d2, int gated, double* __restrict__ partials,
-                       unsigned int* __restrict__ ticket, double* __restrict__ out, unsigned int* __restrict__ hard_count) {
+                       unsigned int* __restrict__ ticket, double* __restrict__ out, unsigned int* __restrict__ hard_count,
+                       pcr_icp_dev_state* __restrict__ st, pcr_icp_loop_args la) {
     __shared__ double s_part[4][PCR_NMOM];
+    if (st && st->stop) return;
     double m[PCR_NMOM];
 #pragma unroll
     for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
@@ -849,8 +858,17 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
     }
     s_red[slice][k] = v;
     __syncthreads();
-    if (slice == 0 && k < PCR_NMOM)
-        out[k] = ((s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k])) + ((s_red[4][k] + s_red[5][k]) + (s_red[6][k] + s_red[7][k]));
+    __shared__ double s_m[PCR_NMOM];
+    if (slice == 0 && k < PCR_NMOM) {
+        const double tot = ((s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k])) + ((s_red[4][k] + s_red[5][k]) + (s_red[6][k] + s_red[7][k]));
+        if (out) out[k] = tot;
+        s_m[k] = tot;
+    }
+    if (st) {
+        // device-resident loop: Procrustes + convergence test here, the next pass reads st->x (kernel boundary orders it)
+        __syncthreads();
+        if (threadIdx.x == 0) pcr::icp_step(st, s_m, gv.origin, la);
+    }
 }
 
 // ------------------------------------------------------------------- host
@@ -862,17 +880,37 @@ struct grid_scratch {
     int64_t nq = 0;
 };
 
-// Runs the search stages on `stream` over the `nq` records at `q` (a whole Morton-sorted cloud or a run of it);
-// leaves res_pos (and res_d2 when asked) on the device.
-static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, hipStream_t stream, unsigned int* hard_count,
-                              const pcr_xform* x, int write_back, double max_d2, bool gated, bool want_d2, bool mark, grid_scratch* sc) {
+static int grid_scratch_alloc(pcr_ctx* ctx, int64_t nq, bool want_d2, unsigned int* hard_count, grid_scratch* sc) {
     int rc;
     sc->nq = nq;
-    const int nblocks = (int)((nq + TQ - 1) / TQ);
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * nq, (void**)&sc->res_pos))) return rc;
-    if (want_d2 && (rc = pcr_dev_alloc(ctx, sizeof(double) * nq, (void**)&sc->res_d2))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(nq), (void**)&sc->hard_list))) return rc;
     sc->hard_count = hard_count;  // zero at context creation, reset by the epilogue kernels
+    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * nq, (void**)&sc->res_pos))) return rc;
+    if (want_d2 && (rc = pcr_dev_alloc(ctx, sizeof(double) * nq, (void**)&sc->res_d2))) {
+        pcr_dev_free(ctx, sc->res_pos, sizeof(unsigned int) * nq);
+        sc->res_pos = nullptr;
+        return rc;
+    }
+    if ((rc = pcr_dev_alloc(ctx, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(nq), (void**)&sc->hard_list))) {
+        pcr_dev_free(ctx, sc->res_pos, sizeof(unsigned int) * nq);
+        if (sc->res_d2) pcr_dev_free(ctx, sc->res_d2, sizeof(double) * nq);
+        sc->res_pos = nullptr; sc->res_d2 = nullptr;
+        return rc;
+    }
+    return PCR_OK;
+}
+
+static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
+    if (sc->res_pos) pcr_dev_free(ctx, sc->res_pos, sizeof(unsigned int) * sc->nq);
+    if (sc->res_d2) pcr_dev_free(ctx, sc->res_d2, sizeof(double) * sc->nq);
+    if (sc->hard_list) pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(sc->nq));
+    sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr;
+}
+
+// Enqueues the search stages on `stream` over the `nq` records at `q` (a whole Morton-sorted cloud or a run of it);
+// leaves res_pos (and res_d2 when the scratch has it) on the device.  `st` != null: device-resident ICP loop.
+static int grid_search_enqueue(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, hipStream_t stream, const pcr_xform* x, int write_back,
+                               double max_d2, bool gated, bool mark, grid_scratch* sc, const pcr_icp_dev_state* st) {
+    const int nblocks = (int)((nq + TQ - 1) / TQ);
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
     if (mark) pcr_prof_mark(ctx, 0);
@@ -881,23 +919,26 @@ static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int
     const int maxc = maxc_env > 0 && maxc_env <= T_MAXC ? maxc_env : T_MAXC;
     static const int pcap_env = getenv("PCR_TILE_PCAP") ? atoi(getenv("PCR_TILE_PCAP")) : 0;
     const unsigned int pcap = pcap_env > 0 ? (unsigned int)pcap_env : (nblocks > 8 * ctx->cu_count ? T_PCAP_LARGE : T_PCAP_SMALL);
-    hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), 0, stream, idx->view, q, (long long)nq, x ? *x : xi, x ? 1 : 0,
-                       write_back, max_d2, gated ? 1 : 0, xcd_remap, pcap, maxc, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug);
+    hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), 0, stream, idx->view, q, (long long)nq, x ? *x : xi, (x || st) ? 1 : 0,
+                       write_back, max_d2, gated ? 1 : 0, xcd_remap, pcap, maxc, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug, st);
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;
     // 8 blocks of 4 waves per CU: twice what is resident at 4 waves per SIMD (4 x CU measured the same, 2 x CU 30 % slower)
     const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
     hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, stream, idx->view, (const work_item*)sc->hard_list,
-                       (const unsigned int*)sc->hard_count, (long long)nq, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug);
+                       (const unsigned int*)sc->hard_count, (long long)nq, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug, st);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
 
-static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
-    pcr_dev_free(ctx, sc->res_pos, sizeof(unsigned int) * sc->nq);
-    if (sc->res_d2) pcr_dev_free(ctx, sc->res_d2, sizeof(double) * sc->nq);
-    pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(sc->nq));
+static int grid_search_launch(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, hipStream_t stream, unsigned int* hard_count,
+                              const pcr_xform* x, int write_back, double max_d2, bool gated, bool want_d2, bool mark, grid_scratch* sc) {
+    int rc = grid_scratch_alloc(ctx, nq, want_d2, hard_count, sc);
+    if (rc) return rc;
+    rc = grid_search_enqueue(ctx, idx, q, nq, stream, x, write_back, max_d2, gated, mark, sc, nullptr);
+    if (rc) grid_scratch_free(ctx, sc);
+    return rc;
 }
 
 int pcr_grid_nn1(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_xform* x, double max_d2, int32_t* d_idx, double* d_d2) {
@@ -939,12 +980,15 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         if (rc) return rc;
         int grid = (int)((nq + 1023) / 1024);  // four queries per thread
         if (grid > ctx->cu_count) grid = ctx->cu_count;
-        if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid))) return rc;
+        if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid))) {
+            grid_scratch_free(ctx, &sc);
+            return rc;
+        }
         // after a write-back pass the cloud already holds the transformed points
         pcr_prof_mark(ctx, 2);
         hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, *x,
                            write_back ? 0 : 1, (const unsigned int*)sc.res_pos, max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
-                           d_moments, sc.hard_count);
+                           d_moments, sc.hard_count, (pcr_icp_dev_state*)nullptr, pcr_icp_loop_args{});
         pcr_prof_mark(ctx, 3);
         pcr_prof_mark(ctx, 4);
         PCR_HIP(ctx, hipGetLastError());
@@ -971,7 +1015,8 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         // slabs go straight to pinned host memory; no ticket
         hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, st, idx->view, (const pcr_pt*)(qc->d + q0), (long long)(q1 - q0), *x,
                            write_back ? 0 : 1, (const unsigned int*)sc[l].res_pos, max_d2, gated ? 1 : 0,
-                           ctx->h_slabs + (size_t)PCR_NMOM * PCR_SLABS_PER_LANE * l, (unsigned int*)nullptr, (double*)nullptr, sc[l].hard_count);
+                           ctx->h_slabs + (size_t)PCR_NMOM * PCR_SLABS_PER_LANE * l, (unsigned int*)nullptr, (double*)nullptr, sc[l].hard_count,
+                           (pcr_icp_dev_state*)nullptr, pcr_icp_loop_args{});
     }
     hipError_t e = hipGetLastError();
     for (int l = 0; l < used; ++l) {
@@ -998,5 +1043,93 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     if (d_moments == ctx->h_pinned) memcpy(ctx->h_pinned, m, sizeof(m));
     else PCR_HIP(ctx, hipMemcpyAsync(d_moments, m, sizeof(m), hipMemcpyHostToDevice, ctx->stream));
     if (d_moments != ctx->h_pinned) PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole ICP loop with the host out of the iteration (Registration/main.py:107-154 / icp_template.py:160-198).
+// Per pass three launches: tile -> hard -> accumulate; the last block of the accumulate kernel sums the slabs in fixed
+// order, solves the 3x3 Procrustes step, tests convergence and writes the next increment into the device state, which
+// the next tile kernel reads.  The host enqueues a CHUNK of passes, then copies the 4.5-KB state back once; passes
+// enqueued behind a stop return at their first instruction.
+int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_icp_params* params, const double T0[16],
+                      pcr_icp_result* res) {
+    const bool gated = (params->max_d2 > 0) && std::isfinite(params->max_d2);
+    int rc = pcr_cloud_morton_sort(ctx, qc, idx->cell);
+    if (rc) return rc;
+    const int64_t nq = qc->n;
+    grid_scratch sc;
+    if ((rc = grid_scratch_alloc(ctx, nq, false, ctx->d_counters + PCR_HARD_COUNTERS, &sc))) return rc;
+    int grid = (int)((nq + 1023) / 1024);  // four queries per thread
+    if (grid > ctx->cu_count) grid = ctx->cu_count;
+    pcr_icp_dev_state* d_st = nullptr;
+    if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid)) ||
+        (rc = pcr_dev_alloc(ctx, sizeof(pcr_icp_dev_state), (void**)&d_st))) {
+        grid_scratch_free(ctx, &sc);
+        return rc;
+    }
+    static_assert(sizeof(pcr_icp_dev_state) <= 8192, "state must fit the pinned staging buffer");
+    pcr_icp_dev_state* h_st = (pcr_icp_dev_state*)ctx->h_state;
+    memset(h_st, 0, sizeof(*h_st));
+    pcr_xform_from_T(T0, &h_st->x);
+    for (int i = 0; i < 16; ++i) h_st->T_total[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) h_st->R_last[3 * i + j] = T0[4 * i + j];
+        h_st->t_last[i] = T0[4 * i + 3];
+    }
+    h_st->first = 1;
+    pcr_icp_loop_args la;
+    la.max_iter = params->max_iter; la.min_iter = params->min_iter;
+    la.compat = params->mode == PCR_ICP_COMPAT_MAIN; la.r_metric = params->r_metric;
+    la.r_thres = params->r_thres; la.t_thres = params->t_thres;
+    hipError_t e = hipMemcpyAsync(d_st, h_st, sizeof(*h_st), hipMemcpyHostToDevice, ctx->stream);
+    pcr_xform xi;
+    pcr_xform_from_T(nullptr, &xi);
+    int enq = 0, launches = 0;
+    // chunk schedule: what is known to run (min_iter) in one go, otherwise 2, 4, 8, ... (the reference's thresholds
+    // usually stop after 1-3 iterations; a no-op pass costs three empty launches)
+    int chunk = params->min_iter > 2 ? params->min_iter : 2;
+    while (e == hipSuccess && rc == PCR_OK && enq < params->max_iter) {
+        if (chunk > params->max_iter - enq) chunk = params->max_iter - enq;
+        if (chunk > 64) chunk = 64;
+        for (int c = 0; c < chunk && rc == PCR_OK; ++c) {
+            rc = grid_search_enqueue(ctx, idx, qc->d, nq, ctx->stream, nullptr, 1, params->max_d2, gated, false, &sc, d_st);
+            if (rc) break;
+            // after the write-back of the tile kernel the cloud already holds the transformed points
+            hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, xi,
+                               0, (const unsigned int*)sc.res_pos, params->max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
+                               (double*)nullptr, sc.hard_count, d_st, la);
+            ++launches;
+        }
+        enq += chunk;
+        if (rc) break;
+        e = hipMemcpyAsync(h_st, d_st, sizeof(*h_st), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess || h_st->stop) break;
+        chunk *= 2;
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    grid_scratch_free(ctx, &sc);
+    pcr_dev_free(ctx, d_st, sizeof(pcr_icp_dev_state));
+    if (rc) return rc;
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
+    double T_cur[16];
+    pcr::T_from_xform(h_st->x, T_cur);
+    if (!la.compat && h_st->status == PCR_OK && !h_st->converged && h_st->it == params->max_iter && params->max_iter > 0) {
+        // icp_template.py:195-198: a non-converged last iteration still updates src_points and homo_mat_total
+        if ((rc = pcr_cloud_transform(ctx, qc, T_cur))) return rc;
+        pcr::T_mul4(T_cur, h_st->T_total, h_st->T_total);
+    }
+    res->iters = h_st->it;
+    res->status = h_st->status;
+    res->n_assoc = h_st->n_assoc;
+    res->cost = h_st->cost;
+    res->mean_d2 = h_st->mean_d2;
+    for (int i = 0; i < h_st->it && i < PCR_ICP_MAX_LOG; ++i) { res->r_diff[i] = h_st->r_diff[i]; res->t_diff[i] = h_st->t_diff[i]; }
+    res->nn_launches = h_st->passes;
+    (void)launches;
+    memcpy(res->T_total, h_st->T_total, sizeof(double) * 16);
+    if (la.compat) memcpy(res->T, T_cur, sizeof(T_cur));
+    else memcpy(res->T, h_st->T_total, sizeof(double) * 16);
     return PCR_OK;
 }

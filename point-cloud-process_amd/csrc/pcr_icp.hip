@@ -4,9 +4,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include "pcr_internal.h"
 #include "pcr_linalg.h"
+#include "pcr_icp_step.h"
 
 extern "C" {
 
@@ -90,26 +92,6 @@ static int icp_pass(pcr_ctx* ctx, const pcr_index* index, pcr_cloud* qc, const p
     return pcr_brute_icp_pass(ctx, index, qc->d, qc->n, x, max_d2, write_back, d_mom);
 }
 
-static void T_from_Rt(const double R[9], const double t[3], double T[16]) {
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * i + j];
-        T[4 * i + 3] = t[i];
-    }
-    T[12] = T[13] = T[14] = 0.0;
-    T[15] = 1.0;
-}
-
-static void T_mul(const double A[16], const double B[16], double C[16]) {
-    double r[16];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            double s = 0;
-            for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j];
-            r[4 * i + j] = s;
-        }
-    memcpy(C, r, sizeof(r));
-}
-
 extern "C" {
 
 int pcr_icp_moments(pcr_ctx* ctx, const pcr_cloud* source, const pcr_index* index, const double* T, double max_d2,
@@ -142,115 +124,71 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
     hipSetDevice(ctx->device);
     memset(res, 0, sizeof(*res));
     const bool compat = params->mode == PCR_ICP_COMPAT_MAIN;
-    double* d_mom = nullptr;
-    int rc = pcr_dev_alloc(ctx, sizeof(double) * PCR_NMOM, (void**)&d_mom);
-    if (rc) return rc;
-
-    double T_cur[16];   // transform to apply at the top of the next pass
-    double T_ret[16];   // what COMPAT returns: T0, then the last increment
-    double T_total[16]; // composed transform actually applied/solved so far
-    memcpy(T_cur, T0, sizeof(T_cur));
-    memcpy(T_ret, T0, sizeof(T_ret));
-    for (int i = 0; i < 16; ++i) T_total[i] = (i % 5 == 0) ? 1.0 : 0.0;
-    double R_last[9], t_last[3];
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) R_last[3 * i + j] = T0[4 * i + j];
-        t_last[i] = T0[4 * i + 3];
-    }
-    bool first = true;
-    bool pending = true;  // T_cur not yet applied to the source
-    int status = PCR_OK;
     PCR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    double nn_ms = 0;
-    int launches = 0;
-    for (int it = 0; it < params->max_iter; ++it) {
-        pcr_xform x;
-        pcr_xform_from_T(T_cur, &x);
-        // main.py:110 / icp_template.py:195: the source is transformed in place, fused into the pass
-        if (ctx->profile) PCR_HIP(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-        // zero-copy read-back: the last block of the pass writes the 160 bytes of moments straight into pinned,
-        // device-mapped host memory (no copy command in the stream, one wait per iteration)
-        rc = icp_pass(ctx, index, source, &x, params->max_d2, 1, ctx->zero_copy ? ctx->h_pinned : d_mom);
-        if (rc) break;
-        if (ctx->profile) PCR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
-        if (!ctx->zero_copy) PCR_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_mom, sizeof(double) * PCR_NMOM, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        float ms = 0;
-        if (ctx->profile) hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3);  // per-pass kernel time only while profiling
-        nn_ms += ms;
-        ++launches;
-        T_mul(T_cur, T_total, T_total);
-        pending = false;
-        const double* m = ctx->h_pinned;
-        const int64_t K = (int64_t)llround(m[0]);
-        res->n_assoc = K;
-        res->mean_d2 = K > 0 ? m[18] / (double)K : 0.0;
-        if (K < 3) {  // main.py:125-127
-            status = PCR_E_TOO_FEW_ASSOC;
-            break;
+    int rc = PCR_OK;
+    static const bool host_loop_env = getenv("PCR_ICP_HOSTLOOP") != nullptr;
+    if (index->kind == PCR_INDEX_GRID && !ctx->profile && ctx->icp_lanes == 1 && !host_loop_env) {
+        // grid index: the whole loop runs on the device, the host only enqueues passes (pcr_grid_search.hip)
+        rc = pcr_grid_icp_loop(ctx, index, source, params, T0, res);
+    } else {
+        // host loop (brute-force index, per-kernel profiling, search lanes): one synchronisation per iteration
+        double* d_mom = nullptr;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(double) * PCR_NMOM, (void**)&d_mom))) return rc;
+        pcr_icp_dev_state st;
+        memset(&st, 0, sizeof(st));
+        pcr_xform_from_T(T0, &st.x);   // transform to apply at the top of the next pass; COMPAT returns it (T0, then the last increment)
+        for (int i = 0; i < 16; ++i) st.T_total[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) st.R_last[3 * i + j] = T0[4 * i + j];
+            st.t_last[i] = T0[4 * i + 3];
         }
-        double R[9], t[3], cost;
-        pcr::kabsch_from_moments(m, index->view.origin, R, t, &cost);
-        res->cost = cost;
-        res->iters = it + 1;
-        // convergence (main.py:149-154)
-        double r_diff;
-        if (params->r_metric == PCR_RMETRIC_GEODESIC) {
-            double tr = 0;
-            for (int i = 0; i < 9; ++i) tr += R[i] * R_last[i];  // trace(R_last^T R)
-            double c = (tr - 1.0) * 0.5;
-            c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
-            r_diff = acos(c);
-        } else {
-            double s = 0;
-            for (int i = 0; i < 9; ++i) s += (R[i] - R_last[i]) * (R[i] - R_last[i]);
-            r_diff = sqrt(s);
-        }
-        double t_diff;
-        if (compat && first) {
-            // main.py:100,150: t is (3,1), t_last is (3,) -> broadcast to 3x3, Frobenius norm
-            double s = 0;
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) s += (t[i] - t_last[j]) * (t[i] - t_last[j]);
-            t_diff = sqrt(s);
-        } else {
-            double s = 0;
-            for (int i = 0; i < 3; ++i) s += (t[i] - t_last[i]) * (t[i] - t_last[i]);
-            t_diff = sqrt(s);
-        }
-        first = false;
-        res->r_diff[it] = r_diff;
-        res->t_diff[it] = t_diff;
-        memcpy(R_last, R, sizeof(R_last));
-        memcpy(t_last, t, sizeof(t_last));
-        T_from_Rt(R, t, T_cur);
-        memcpy(T_ret, T_cur, sizeof(T_ret));
-        pending = true;
-        const bool converged = (r_diff <= params->r_thres && t_diff <= params->t_thres) && (it + 1 >= params->min_iter);
-        if (converged) break;
-        if (!compat && it + 1 == params->max_iter) {
-            // icp_template.py:195-198: a non-converged last iteration still updates src_points and homo_mat_total
-            rc = pcr_cloud_transform(ctx, source, T_cur);
+        st.first = 1;
+        pcr_icp_loop_args la;
+        la.max_iter = params->max_iter; la.min_iter = params->min_iter; la.compat = compat ? 1 : 0; la.r_metric = params->r_metric;
+        la.r_thres = params->r_thres; la.t_thres = params->t_thres;
+        double nn_ms = 0;
+        for (int it = 0; it < params->max_iter && !st.stop; ++it) {
+            // main.py:110 / icp_template.py:195: the source is transformed in place, fused into the pass
+            if (ctx->profile) PCR_HIP(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+            // zero-copy read-back: the pass writes the 160 bytes of moments straight into pinned, device-mapped host memory
+            rc = icp_pass(ctx, index, source, &st.x, params->max_d2, 1, ctx->zero_copy ? ctx->h_pinned : d_mom);
             if (rc) break;
-            T_mul(T_cur, T_total, T_total);
-            pending = false;
+            if (ctx->profile) PCR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
+            if (!ctx->zero_copy) PCR_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_mom, sizeof(double) * PCR_NMOM, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            float ms = 0;
+            if (ctx->profile) hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3);  // per-pass kernel time only while profiling
+            nn_ms += ms;
+            pcr::icp_step(&st, ctx->h_pinned, index->view.origin, la);
         }
+        pcr_dev_free(ctx, d_mom, sizeof(double) * PCR_NMOM);
+        if (rc) return rc;
+        double T_cur[16];
+        pcr::T_from_xform(st.x, T_cur);
+        if (!compat && st.status == PCR_OK && !st.converged && st.it == params->max_iter && params->max_iter > 0) {
+            // icp_template.py:195-198: a non-converged last iteration still updates src_points and homo_mat_total
+            if ((rc = pcr_cloud_transform(ctx, source, T_cur))) return rc;
+            pcr::T_mul4(T_cur, st.T_total, st.T_total);
+        }
+        res->iters = st.it;
+        res->status = st.status;
+        res->n_assoc = st.n_assoc;
+        res->cost = st.cost;
+        res->mean_d2 = st.mean_d2;
+        for (int i = 0; i < st.it; ++i) { res->r_diff[i] = st.r_diff[i]; res->t_diff[i] = st.t_diff[i]; }
+        res->nn_kernel_ms = nn_ms;
+        res->nn_launches = st.passes;
+        memcpy(res->T_total, st.T_total, sizeof(st.T_total));
+        if (compat) memcpy(res->T, T_cur, sizeof(T_cur));
+        else memcpy(res->T, st.T_total, sizeof(st.T_total));
     }
-    (void)pending;
+    if (rc) return rc;
     PCR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     PCR_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float loop_ms = 0;
     hipEventElapsedTime(&loop_ms, ctx->ev0, ctx->ev1);
-    pcr_dev_free(ctx, d_mom, sizeof(double) * PCR_NMOM);
-    if (rc) return rc;
-    res->status = status;
     res->device_ms = loop_ms;
-    res->nn_kernel_ms = nn_ms;
-    res->nn_launches = launches;
-    memcpy(res->T_total, T_total, sizeof(T_total));
-    if (compat) memcpy(res->T, T_ret, sizeof(T_ret));
-    else memcpy(res->T, T_total, sizeof(T_total));
-    return status;
+    return res->status;
 }
 
 int pcr_procrustes(const double* A, const double* B, int64_t k, double R_out[9], double t_out[3], double* cost_out) {

@@ -89,10 +89,12 @@ struct pcr_ctx {
     // grow-only caching allocator (device) keyed by size; avoids hipMalloc in the ICP loop
     struct blk { void* p; size_t sz; };
     std::vector<blk> free_list;
+    std::vector<blk> live;       // blocks handed out, with their TRUE capacity (a reused block may be larger than asked for)
     std::vector<void*> arenas;   // 256-MiB hipMalloc chunks the blocks are carved from
     size_t arena_cap = 0, arena_used = 0;
     // pinned host scratch for the per-iteration moment read-back
     double* h_pinned = nullptr;
+    void* h_state = nullptr;              // pinned 8-KiB staging buffer of the device-resident ICP state
     size_t h_pinned_bytes = 0;
     int icp_lanes = 1;                    // runs of the source searched on separate streams per ICP pass (PCR_ICP_LANES)
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -162,3 +164,28 @@ PCR_HIDDEN int pcr_brute_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q,
                                   double max_d2, int write_back, double* d_moments);
 
 constexpr int PCR_NMOM = 20;  // K, Sa[3], Sb[3], Sba[9], Saa, Sbb, Sd2, pad
+
+// Device-resident state of the ICP loop (grid path): the last block of the accumulate kernel solves the Procrustes
+// step, tests convergence (Registration/main.py:131-154) and leaves the next pass's transform here, so the host
+// enqueues several iterations per synchronisation; passes enqueued behind a stop are no-ops.
+struct __attribute__((aligned(16))) pcr_icp_dev_state {
+    pcr_xform x;          // transform the NEXT pass applies = last solved increment (T_cur / T_ret of the host loop)
+    double T_total[16];   // composed transform applied so far
+    double R_last[9], t_last[3];
+    double cost, mean_d2;
+    long long n_assoc;
+    int it;               // Procrustes solves performed
+    int stop;             // no further pass may run (converged, max_iter reached, or too few associations)
+    int converged;
+    int status;
+    int first;            // main.py:100,150: the first t_diff broadcasts (3,1)-(3,)
+    int passes;           // association passes executed (the source has been transformed this many times)
+    double r_diff[PCR_ICP_MAX_LOG], t_diff[PCR_ICP_MAX_LOG];
+};
+struct pcr_icp_loop_args {
+    int max_iter, min_iter, compat, r_metric;
+    double r_thres, t_thres;
+};
+// whole ICP loop on the device (grid index); fills res like the host loop of pcr_icp
+PCR_HIDDEN int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_icp_params* params, const double T0[16],
+                                 pcr_icp_result* res);
