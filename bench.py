@@ -9,10 +9,16 @@ the target index are resident in HBM before the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--nn grid|brute]
 
-N > 1 is launched by torch.distributed.run (one process per GPU): every rank
-registers its own independent pair (the path shards across pairs, never inside
-one), results are gathered with one all_gather over RCCL, the
-timing is the max over ranks.  Rank 0 prints ONE JSON line.
+--gpus N > 1 without a launcher: this process starts N ranks ITSELF (a child
+`python -m torch.distributed.run --nproc-per-node N ... bench.py`, before any
+GPU call is made here) and relays their output; under torch.distributed.run
+(WORLD_SIZE set) it is one of the ranks.  One process per GPU: every rank
+registers its own independent 120k pair (the path shards across pairs, never
+inside one), results are gathered with one all_gather over
+RCCL, the timing is the max over ranks.  A second block, "batch256", runs
+BASELINE configs[3] (256 registration_dataset-shaped pairs of 20 000 6-float
+records) through register_batch: block-sharded over the ranks, one RCCL
+all_gather of the result records.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -20,6 +26,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +44,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # algorithmic HBM bytes per correspondence of the grid pass:
 # 32 B source record read + 32 B written back in place + 32 B matched target record + 4 B result slot
 GRID_BYTES_PER_CORR = 100.0
+# VALU roofline of the tile kernel's filter (MI355X_MICROARCH.md: 4 SIMD-32 per CU, 2.4 GHz, 157.3 TFLOP/s f32 vector =
+# 256 CUs x 4 SIMDs x 32 lanes x 2 flop): lane-operations the binary32 filter cannot do without, per (query, candidate)
+# pair: 3 subtractions + 1 multiply + 2 fused multiply-adds + 1 minimum
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
+FILTER_LANE_OPS_PER_PAIR = 7.0
+BATCH_PAIRS, BATCH_POINTS = 256, 20_000
+
+
+def launch_ranks(n):
+    """Start n ranks of this script under torch.distributed.run and relay their output.  Runs BEFORE this process makes
+    any GPU call (a process that has initialised the GPU must never be replaced or re-exec'd)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(src, tgt, budget_s=12.0, max_iters=40):
@@ -93,10 +120,12 @@ def parity_gates(pkg, index, src, tgt):
             "Rt_frobenius_vs_cpu_after_10_iters": float(np.linalg.norm(r["T_total"] - T_cpu)), "tolerance": 1e-4}
 
 
-def run_icp_steps(pkg, index, src_host, steps, ctx):
-    """Exactly `steps` ICP iterations (thresholds off), device-resident inputs.  Returns dict."""
+def run_icp_steps(pkg, index, src_host, steps, ctx, sd=None):
+    """Exactly `steps` ICP iterations (thresholds off), device-resident inputs.  `sd`: a source cloud already uploaded
+    and laid out (the timed run hands one in so that the set-up stays outside the timed region).  Returns dict."""
     out = {"iters": 0, "device_ms": 0.0, "nn_kernel_ms": 0.0, "nn_launches": 0}
-    sd = pkg.DeviceCloud.upload(src_host, ctx).prepare(index)  # resident + laid out before the timed region
+    if sd is None:
+        sd = pkg.DeviceCloud.upload(src_host, ctx).prepare(index)  # resident + laid out before the timed region
     T0 = np.eye(4)
     ctx.sync()
     t0 = time.perf_counter()
@@ -156,6 +185,73 @@ def concurrent_leg(pkg, dev_id, src, tgt, n_pairs, steps):
             "unit": "correspondences/s", "ms_per_icp_iter_per_pair": 1e3 * el / steps}
 
 
+def filter_pairs_per_pass(pkg, dev_id, src, tgt, cell):
+    """(query, staged candidate) pairs the tile kernel's filter evaluates in one pass over the bench pair: read from the
+    kernel's own per-tile stamps (PCR_DEBUG_STAMPS) on a throw-away context, untimed."""
+    import ctypes as C
+
+    os.environ["PCR_DEBUG_STAMPS"] = "1"
+    try:
+        c = pkg.Context(dev_id)
+    finally:
+        del os.environ["PCR_DEBUG_STAMPS"]
+    idx = pkg.TargetIndex(pkg.DeviceCloud.upload(tgt, c), cell=cell, ctx=c)
+    sd = pkg.DeviceCloud.upload(src, c).prepare(idx)
+    pkg.icp_device(sd, idx, np.eye(4), mode="total", max_iter=2, r_thres=-1.0, t_thres=-1.0, max_d2=MAX_D2, min_iter=2)
+    nb = (len(src) + 63) // 64
+    buf = np.zeros(nb * 4, dtype=np.uint64)
+    L = pkg._lib
+    L.check(L.lib().pcr_debug_read(c.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size))
+    P = buf.reshape(nb, 4)[:, 1].astype(np.int64)
+    staged = P[P != 0xFFFFFFFF]
+    sd.free()
+    idx.free()
+    c.close()
+    return float(64 * staged.sum()), float(np.mean(staged))
+
+
+def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
+    """BASELINE configs[3]: 256 pairs x 20 000-point 6-float records (Registration/main.py:190-216 is the loop being
+    sharded) through register_batch -- upload, index build and ICP of every pair inside the timed region, one all_gather
+    of the result records.  Two passes: the reference's own stopping rule (compat, thresholds 0.5: 1-2 iterations) and a
+    converged run (composed transform, thresholds 1e-6)."""
+    batch = importlib.import_module("point-cloud-process_amd.batch")
+    lo, hi = batch.shard_range(BATCH_PAIRS, rank, world)
+    mine = pkg.synthetic.registration_batch_6f(BATCH_PAIRS, BATCH_POINTS, seed=1000, indices=range(lo, hi))
+    pairs = [None] * BATCH_PAIRS
+    truth = {}
+    for i, (s6, t6, Tt) in zip(range(lo, hi), mine):
+        pairs[i] = (s6, t6, None)
+        truth[i] = Tt
+    out = {"pairs": BATCH_PAIRS, "points_per_cloud": BATCH_POINTS, "record": "6 x f32 (x,y,z,nx,ny,nz)", "streams_per_gpu": streams,
+           "pairs_per_gpu": hi - lo}
+    for tag, kw in (("compat", dict(mode="compat")), ("converged", dict(mode="total", max_iter=50, r_thres=1e-6, t_thres=1e-6))):
+        fn = batch.gpu_register_fn(device=dev_id, streams=streams, **kw)
+        for k in range(min(streams, hi - lo)):  # warm every context (arena, pinned buffers, code objects), untimed
+            fn(k, pairs[lo + k][0], pairs[lo + k][1], None)
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        res = batch.register_batch(pairs, register_fn=fn)
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tm = torch.tensor([el], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+        iters = np.array([r["iters"] for r in res])
+        errs = [float(np.linalg.norm(res[i]["T"] - truth[i])) for i in truth] if tag == "converged" else []
+        out[tag] = {"seconds": el, "pairs_per_s": BATCH_PAIRS / el, "pairs_per_s_per_gpu": BATCH_PAIRS / el / world,
+                    "correspondences_per_s": float(iters.sum()) * BATCH_POINTS / el, "mean_iters": float(iters.mean()),
+                    "results_gathered": len(res)}
+        if errs:
+            out[tag]["max_T_error_vs_truth_local_share"] = max(errs)
+    # algorithmic HBM bytes of the batch (SURVEY 8d): both clouds of every pair as 16-B records
+    out["algorithmic_bytes"] = BATCH_PAIRS * 2 * BATCH_POINTS * 16
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,7 +265,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-brute", action="store_true", help="skip the brute-force MFMA leg")
     ap.add_argument("--in-flight", type=int, default=4, help="pairs in flight for the supplementary concurrent leg (0 = skip)")
+    ap.add_argument("--no-batch", action="store_true", help="skip the batch256 block (BASELINE configs[3])")
+    ap.add_argument("--batch-streams", type=int, default=4, help="pairs in flight per GPU in the batch256 block")
     a = ap.parse_args()
+
+    if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,9 +308,15 @@ def main():
     if dist is not None:  # warm the collective too (communicator and kernel set-up are one-off costs)
         wrec = torch.zeros(18, dtype=torch.float64, device=tdev)
         dist.all_gather([torch.zeros_like(wrec) for _ in range(world)], wrec)
+    # set-up of the timed run, reported separately: upload of the source (PCIe) + Morton lay-out for this index
+    ctx.sync()
+    ts = time.perf_counter()
+    sd_timed = pkg.DeviceCloud.upload(src, ctx).prepare(index)
+    ctx.sync()
+    setup_ms = 1e3 * (time.perf_counter() - ts)
     barrier()
     t0 = time.perf_counter()
-    r = run_icp_steps(pkg, index, src, a.steps, ctx)
+    r = run_icp_steps(pkg, index, src, a.steps, ctx, sd=sd_timed)
     # result gather: 16 doubles + iters + n_assoc per rank (RCCL all_gather), inside the timed region
     if dist is not None:
         rec = torch.zeros(18, dtype=torch.float64, device=tdev)
@@ -224,6 +331,10 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    batch256 = None
+    if not a.no_batch and a.nn == "grid":
+        batch256 = batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, a.batch_streams)
 
     if rank == 0:
         n_src = a.points
@@ -248,13 +359,14 @@ def main():
             algo_bytes = GRID_BYTES_PER_CORR * n_src
             traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
                 traffic = pmc["kernels"][dom].get("hbm_bytes") if a.points == N_POINTS else None
             except Exception:
                 traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": algo_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / dom_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                        "note": "working set (2 x 3.8 MB) is L2/MALL resident; this kernel is latency/issue bound, not HBM bound"}
+                        "traffic_source": "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc passes of the same command), not measured in this run",
+                        "note": "working set (2 x 3.8 MB) is L2/MALL resident; this kernel is VALU-issue and latency bound, not HBM bound: see roofline_valu"}
         else:
             flops = 8.0 * n_src * a.points
             roofline = {"bound": "mfma", "kernel": dom, "achieved": flops / dom_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -279,9 +391,25 @@ def main():
             "device_ms_per_iter": r["device_ms"] / r["iters"],
             "pass_kernels_ms_per_iter": rp["nn_kernel_ms"] / max(rp["nn_launches"], 1),  # from the profiled (untimed) run
             "kernel_us": kern,
+            "setup_ms_not_timed": setup_ms,
             "n_assoc_last": int(r["n_assoc"]),
             "roofline": roofline,
         }
+        if a.nn == "grid" and "grid_tile_kernel" in kern:
+            try:
+                fpairs, mean_p = filter_pairs_per_pass(pkg, dev_id, src, tgt, a.cell)
+                tile_s = kern["grid_tile_kernel"] * 1e-6
+                ach = fpairs * FILTER_LANE_OPS_PER_PAIR / tile_s
+                line["roofline_valu"] = {"bound": "valu", "kernel": "grid_tile_kernel", "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
+                                         "unit": "Tlane-op/s (f32)", "frac": ach / VALU_PEAK_LANE_OPS,
+                                         "filter_pairs_per_launch": fpairs, "mean_staged_points_per_tile": mean_p,
+                                         "lane_ops_per_pair": FILTER_LANE_OPS_PER_PAIR,
+                                         "note": "minimal binary32 filter arithmetic over the kernel's measured duration; directory, staging and the "
+                                                 "binary64 verification are overhead on top of it"}
+            except Exception as e:  # diagnostics only
+                line["roofline_valu"] = {"error": repr(e)}
+        if batch256 is not None:
+            line["batch256"] = batch256
         if a.nn == "brute":
             line["candidate_pairs_per_s"] = float(n_src) * a.points * a.steps * world / elapsed
         # brute-force MFMA leg (candidate pairs/s + MFMA roofline), N = 1 only
@@ -313,6 +441,7 @@ def main():
             if a.nn == "grid" and a.points <= 200_000:
                 line["parity"] = parity_gates(pkg, index, src, tgt)
         print(json.dumps(line))
+    sd_timed.free()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,6 +9,7 @@ never split.
 """
 from __future__ import annotations
 
+import queue
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -51,7 +52,7 @@ def gpu_register_fn(device=0, nn="grid", mode="compat", streams=1, **icp_kw):
     ctxs = [Context(device) for _ in range(max(1, int(streams)))]
 
     def run(slot, src, tgt, T0):
-        ctx = ctxs[slot % len(ctxs)]
+        ctx = ctxs[slot]  # the caller owns `slot` for the duration of the call (register_batch hands slots out through a queue)
         sd = DeviceCloud.upload(src, ctx)
         index = TargetIndex(DeviceCloud.upload(tgt, ctx), kind=nn, ctx=ctx)
         try:
@@ -61,6 +62,7 @@ def gpu_register_fn(device=0, nn="grid", mode="compat", streams=1, **icp_kw):
             index.free()
 
     run.streams = len(ctxs)
+    run.device = int(device)
     return run
 
 
@@ -93,10 +95,20 @@ def register_batch(pairs, register_fn=None, group=None, device=None, streams=4, 
         register_fn = gpu_register_fn(device=device, streams=streams, **kw)
     workers = int(getattr(register_fn, "streams", 1))
     local = np.zeros((hi - lo, RECORD))
+    # A pcr_ctx is not thread-safe: a slot (= one context, one HIP stream) belongs to exactly one task at a time.
+    # Slots are taken from a queue when a task STARTS and given back when it ends -- binding them to the task index
+    # would let a fast thread start task i + workers on a context a slow thread is still using.
+    slots = queue.Queue()
+    for w in range(workers):
+        slots.put(w)
 
     def one(i):
         src, tgt, T0 = pairs[i]
-        res = register_fn((i - lo) % workers, src, tgt, T0)
+        slot = slots.get()
+        try:
+            res = register_fn(slot, src, tgt, T0)
+        finally:
+            slots.put(slot)
         local[i - lo] = pack_result(i, res)
 
     if workers > 1 and hi - lo > 1:
@@ -112,7 +124,16 @@ def register_batch(pairs, register_fn=None, group=None, device=None, streams=4, 
 
     share = (n + world - 1) // world
     use_cuda = dist.get_backend(group) == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        # the gather buffer lives on the SAME device as this rank's pcr contexts (not on whatever torch's current device is)
+        dev_id = getattr(register_fn, "device", device)
+        if dev_id is None:
+            import os
+
+            dev_id = int(os.environ.get("LOCAL_RANK", "0"))
+        dev = torch.device("cuda", int(dev_id))
+    else:
+        dev = torch.device("cpu")
     buf = torch.full((share, RECORD), -1.0, dtype=torch.float64, device=dev)
     if hi > lo:
         buf[: hi - lo] = torch.from_numpy(local).to(dev)

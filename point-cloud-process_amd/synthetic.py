@@ -20,6 +20,7 @@ __all__ = [
     "rigid_transform",
     "object_cloud",
     "registration_pair_6f",
+    "registration_batch_6f",
 ]
 
 
@@ -56,7 +57,7 @@ def _ray_boxes(origins, dirs, lo, hi):
     return t.min(axis=1)
 
 
-def kitti_like_scan(n_points=120_000, seed=0, sensor_pose=None):
+def kitti_like_scan(n_points=120_000, seed=0, sensor_pose=None, pad=True):
     """One HDL-64-like sweep ray-cast against a ground plane and random boxes.
 
     Returns float32 (n_points, 3) in the sensor frame (like a KITTI .bin's xyz
@@ -107,6 +108,8 @@ def kitti_like_scan(n_points=120_000, seed=0, sensor_pose=None):
     t = t + rng.normal(0, 0.02, t.shape[0])
     pts = (d_local * t[:, None])[keep]
 
+    if not pad and pts.shape[0] < n_points:
+        return np.ascontiguousarray(pts, dtype=np.float32)   # every return of the sweep, no padding
     if pts.shape[0] >= n_points:
         sel = np.sort(rng.choice(pts.shape[0], n_points, replace=False))
         pts = pts[sel]
@@ -167,3 +170,38 @@ def registration_pair_6f(n_points=20_000, seed=1000):
         return out
 
     return six(src), six(tgt), T_true
+
+
+def registration_batch_6f(n_pairs=256, n_points=20_000, seed=1000, n_base=2, indices=None):
+    """BASELINE configs[3]: ``n_pairs`` registration_dataset-style pairs of (n,6) float32 records.
+
+    Ray-casting a sweep costs ~1 s, so the batch is derived from ``n_base`` base sweep pairs of the shared static
+    world: pair i takes its own random ``n_points`` subset of each base sweep (different points, same scene), its own
+    range noise and its own small rigid offset between source and target -- independent registration problems with
+    the statistics of one scan pair.  ``indices`` limits generation to a rank's share (returns that many pairs).
+    Returns a list of (src (n,6) f32, tgt (n,6) f32, T_true (4,4) f64).
+    """
+    base = []
+    for b in range(n_base):
+        T_b = rigid_transform((0.1, 0.2, 1.0), np.deg2rad(1.0 + 0.3 * b), (0.3 + 0.1 * b, -0.15, 0.03))
+        tgt = kitti_like_scan(10**9, seed=2 * (seed + b), sensor_pose=np.eye(4), pad=False).astype(np.float64)
+        src = kitti_like_scan(10**9, seed=2 * (seed + b) + 1, sensor_pose=T_b, pad=False).astype(np.float64)
+        base.append((src, tgt, T_b))
+    out = []
+    for i in (range(n_pairs) if indices is None else indices):
+        rng = np.random.default_rng(seed * 7919 + i)
+        src, tgt, T_b = base[i % n_base]
+        ang = rng.uniform(0.2, 1.5)
+        axis = np.array([rng.normal(0, 0.1), rng.normal(0, 0.1), 1.0])
+        D = rigid_transform(axis, np.deg2rad(ang), rng.uniform(-0.3, 0.3, 3) * np.array([1.0, 1.0, 0.1]))
+        s = src[np.sort(rng.choice(len(src), n_points, replace=False))] + rng.normal(0, 0.01, (n_points, 3))
+        t = tgt[np.sort(rng.choice(len(tgt), n_points, replace=False))] + rng.normal(0, 0.01, (n_points, 3))
+        # p_tgt = T_b p_src; move the source by D^-1 so that T_true = T_b D
+        s = (s - D[:3, 3]) @ D[:3, :3]
+        rec_s = np.zeros((n_points, 6), dtype=np.float32)
+        rec_t = np.zeros((n_points, 6), dtype=np.float32)
+        rec_s[:, :3] = s
+        rec_t[:, :3] = t
+        rec_s[:, 5] = rec_t[:, 5] = 1.0
+        out.append((rec_s, rec_t, T_b @ D))
+    return out

@@ -138,6 +138,24 @@ def test_register_batch_single_gpu_streams(pcp, oracle, syn):
         assert np.linalg.norm(r["T"] - ref["T"]) < 1e-9
 
 
+def test_register_batch_unequal_pairs_match_serial(pcp, syn):
+    """12 pairs of very different sizes and iteration counts on 3 streams: every result equals the serial run bit for
+    bit (a context shared by two in-flight pairs would corrupt the pinned read-back or the scratch)."""
+    rng = np.random.default_rng(5)
+    pairs = []
+    for i in range(12):
+        n = int(rng.choice([600, 3000, 12000, 25000]))
+        s, t, _ = syn.perturbed_pair(n, seed=300 + i, angle_deg=float(rng.uniform(0.5, 6.0)), t=tuple(rng.uniform(-0.8, 0.8, 3) * [1, 1, 0.1]))
+        pairs.append((s, t, None))
+    kw = dict(mode="total", max_iter=40, r_thres=1e-6, t_thres=1e-6)
+    serial = pcp.register_batch(pairs, streams=1, **kw)
+    threaded = pcp.register_batch(pairs, streams=3, **kw)
+    assert len({r["iters"] for r in serial}) > 2          # the pairs really differ in work
+    for a, b in zip(serial, threaded):
+        assert a["pair"] == b["pair"] and a["iters"] == b["iters"] and a["n_assoc"] == b["n_assoc"]
+        assert np.array_equal(a["T"], b["T"])
+
+
 def test_dbscan_matches_reference_labels(pcp, oracle, syn):
     """Cluster_dbscan/dbscan.py: labels equal the reference's own output (goldens), numbering and noise quirks included."""
     g = load_golden("dbscan.npz")
