@@ -202,12 +202,11 @@ def filter_pairs_per_pass(pkg, dev_id, src, tgt, cell):
     buf = np.zeros(nb * 4, dtype=np.uint64)
     L = pkg._lib
     L.check(L.lib().pcr_debug_read(c.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size))
-    P = buf.reshape(nb, 4)[:, 1].astype(np.int64)
-    staged = P[P != 0xFFFFFFFF]
+    pairs = buf.reshape(nb, 4)[:, 1].astype(np.float64)   # (query, staged candidate) pairs of every block of 4 wave tiles
     sd.free()
     idx.free()
     c.close()
-    return float(64 * staged.sum()), float(np.mean(staged))
+    return float(pairs.sum()), float(pairs.sum() / len(src))
 
 
 def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
@@ -402,7 +401,7 @@ def main():
                 ach = fpairs * FILTER_LANE_OPS_PER_PAIR / tile_s
                 line["roofline_valu"] = {"bound": "valu", "kernel": "grid_tile_kernel", "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
                                          "unit": "Tlane-op/s (f32)", "frac": ach / VALU_PEAK_LANE_OPS,
-                                         "filter_pairs_per_launch": fpairs, "mean_staged_points_per_tile": mean_p,
+                                         "filter_pairs_per_launch": fpairs, "mean_candidates_per_query": mean_p,
                                          "lane_ops_per_pair": FILTER_LANE_OPS_PER_PAIR,
                                          "note": "minimal binary32 filter arithmetic over the kernel's measured duration; directory, staging and the "
                                                  "binary64 verification are overhead on top of it"}

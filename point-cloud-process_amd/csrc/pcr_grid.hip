@@ -299,6 +299,11 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
         v.btable[l] = idx->btables[l];
         v.bmask[l] = idx->bcaps[l] - 1;
     }
+    // device copy of the view: the search kernels read it through a pointer (scalar loads of the few fields a wave
+    // needs) instead of carrying its 400 bytes in kernel-argument SGPRs
+    if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_grid_view), (void**)&idx->d_view))) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(idx->d_view, &idx->view, sizeof(pcr_grid_view), hipMemcpyHostToDevice, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // idx->view is pageable host memory
     return PCR_OK;
 }
 
@@ -343,6 +348,8 @@ int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell) {
 }
 
 void pcr_grid_free(pcr_ctx* ctx, pcr_index* idx) {
+    if (idx->d_view) pcr_dev_free(ctx, idx->d_view, sizeof(pcr_grid_view));
+    idx->d_view = nullptr;
     pcr_dev_free(ctx, idx->sorted, sizeof(pcr_pt) * idx->n);
     idx->sorted = nullptr;
     for (int l = 0; l < PCR_MAX_LEVELS; ++l) {

@@ -43,8 +43,9 @@ constexpr long long ID_NONE = 0x7fffffffffffffffll;
 constexpr int H_NLIST = 32;
 constexpr int H_CSTRIDE = 32;
 __host__ __device__ static inline unsigned int hard_list_cap(long long nq) {
-    const long long tiles = (nq + 63) / 64;
-    return (unsigned int)(((tiles + H_NLIST - 1) / H_NLIST) * 64);
+    // tiles (of 64 or 16 queries) append to list (tile % H_NLIST): room for every query of the lists' fair share of tiles
+    const long long tiles = (nq + 15) / 16;
+    return (unsigned int)(((tiles + H_NLIST - 1) / H_NLIST) * 16 + 64);
 }
 
 template <int G>
@@ -454,6 +455,460 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
         dbg[blockIdx.x * 4 + 1] = (level >= 0) ? sm.total : 0xffffffffu;
         dbg[blockIdx.x * 4 + 2] = ((unsigned long long)(level + 1) << 32) | (unsigned)sm.ncell;
         dbg[blockIdx.x * 4 + 3] = n_unres;
+    }
+}
+
+// --------------------------------------------------------------- wave tile
+// Second-generation tile stage: ONE WAVE = one tile of 16 consecutive queries, no block-level barrier anywhere.
+// Why: with 64-query tiles every query was compared with the union of 64 neighbourhoods (~980 staged points per
+// query on a KITTI scan: the kernel spent its time at the binary32 VALU peak on candidates no query needed), and the
+// four waves of a block marched through load / directory / staging / filter in lockstep, so all resident tiles hit
+// the memory system and then the VALU together.  A 16-query tile's box holds 3-4x fewer points at the same
+// directory and staging cost per query, and independent waves de-synchronise by themselves.
+//   lanes: query = lane & 15 (four copies), candidate slice = lane >> 4.
+//   Up to WT_PASSES passes.  In every pass each still-open query claims a cube of half-width rho around itself:
+//   rho = sqrt(bound) once it has a candidate (bound = the filter's rigorous upper bound U on the winner's squared
+//   distance), otherwise cell0 * 4^pass (a guess, capped by the gate).  The pass box is the bounding box of the
+//   claimed cubes in cells of the finest level that keeps it within WT_MAXC cells / 64 two-cell blocks; everything in
+//   the box is staged and filtered.  A query is proven when the ball of radius sqrt(min(U, gate)) lies inside the box
+//   that was actually staged and the filter's second-best exceeds U.  What is still open after the last pass
+//   (ambiguous filter results, boxes with too many points, clamped coordinates) goes to the hard stage.
+#ifndef PCR_WT_Q
+#define PCR_WT_Q 16
+#endif
+constexpr int WT_Q = PCR_WT_Q;      // queries per wave tile (16 or 32)
+constexpr int WT_MAXC = 128;        // cells in a wave-tile box
+constexpr int WT_PR = 192;          // points staged per round (3 chunks of 64, loaded back to back)
+constexpr int WT_PASSES = 3;
+constexpr int WT_ROUNDS_SMALL = 4, WT_ROUNDS_LARGE = 12;
+
+struct wtile_lds {
+    alignas(16) float px[WT_PR + 8], py[WT_PR + 8], pz[WT_PR + 8];
+    unsigned int ppos[WT_PR];
+    unsigned int c_start[WT_MAXC];
+    unsigned int c_off[WT_MAXC + 1];
+    unsigned short own[WT_PR];
+};
+
+// LDS hand-off between the lanes of ONE wave: LDS operations of a wave execute in order, so no hardware wait is
+// needed, but the compiler must neither forward a lane's own earlier store to its load nor move accesses across
+__device__ static inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Wave64 inclusive scans on the DPP network (row_shr 1/2/4/8, then row_bcast15 / row_bcast31): six VALU
+// instructions, no LDS traffic (a __shfl_up scan is six ds_bpermute round trips).
+template <int CTRL, int ROW_MASK>
+__device__ static inline unsigned int dpp_u32(unsigned int identity, unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ static inline unsigned int wave_incl_scan_add(unsigned int v) {
+    v += dpp_u32<0x111, 0xf>(0u, v);
+    v += dpp_u32<0x112, 0xf>(0u, v);
+    v += dpp_u32<0x114, 0xf>(0u, v);
+    v += dpp_u32<0x118, 0xf>(0u, v);
+    v += dpp_u32<0x142, 0xa>(0u, v);   // row_bcast15 into rows 1 and 3
+    v += dpp_u32<0x143, 0xc>(0u, v);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ static inline unsigned int wave_incl_scan_max(unsigned int v) {
+    v = max(v, dpp_u32<0x111, 0xf>(0u, v));
+    v = max(v, dpp_u32<0x112, 0xf>(0u, v));
+    v = max(v, dpp_u32<0x114, 0xf>(0u, v));
+    v = max(v, dpp_u32<0x118, 0xf>(0u, v));
+    v = max(v, dpp_u32<0x142, 0xa>(0u, v));
+    v = max(v, dpp_u32<0x143, 0xc>(0u, v));
+    return v;
+}
+// all-reduce inside every row of 16 lanes (= the 16 queries of a candidate slice): quad swaps, half mirror, mirror
+__device__ static inline int row16_min(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror
+    return v;
+}
+__device__ static inline int row16_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+
+__device__ static inline unsigned int wave_excl_scan_u32(unsigned int v, int lane, unsigned int* total) {
+    const unsigned int inc = wave_incl_scan_add(v);
+    *total = __builtin_amdgcn_readlane((int)inc, 63);
+    return inc - v;
+}
+
+struct wt_xyz { double x, y, z; };  // the 24 coordinate bytes of a pcr_pt record
+
+// pointers read from the device copy of the grid view are generic; tell the compiler they are global memory
+template <typename T>
+__device__ static inline const T* as_global(const T* p) {
+    return (const T*)(const __attribute__((address_space(1))) T*)p;
+}
+
+__global__ void __launch_bounds__(256)
+grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
+                  int gated, int xcd_remap, unsigned int pcap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2,
+                  work_item* __restrict__ hard_list, unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg,
+                  const pcr_icp_dev_state* __restrict__ st, int use_prev) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ wtile_lds s_lds[4];
+    if (st) {
+        if (st->stop) return;
+        x = st->x;
+    }
+    const pcr_grid_view& gv = *gvp;  // uniform address: fields arrive by scalar loads when they are needed
+    const pcr_pt* __restrict__ g_pts = as_global(gv.pts);
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = t_start;
+#define WT_STAMP(i) do { if (dbg) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_ph[i] += t_now - t_last; t_last = t_now; } } while (0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    wtile_lds* L = &s_lds[wave];
+    unsigned int blk = blockIdx.x;
+    if (xcd_remap) {  // every XCD (own L2) gets one contiguous run of the Morton-sorted queries
+        const unsigned int per = gridDim.x >> 3, main = per << 3;
+        if (blk < main) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    const long long qi = ((long long)blk * 4 + wave) * WT_Q + (lane & (WT_Q - 1));
+    const bool qvalid = qi < nq;
+    double ax = 0, ay = 0, az = 0;
+    bool clamped = false;
+    if (qvalid) {
+        const pcr_pt p = q[qi];
+        ax = p.x; ay = p.y; az = p.z;
+        if (has_x) {
+            xform_apply(x, p, &ax, &ay, &az);
+            // in-place transform of the source (main.py:110); every lane of this wave has loaded its record by now
+            // and no other wave reads these 16 records
+            if (write_back && lane < WT_Q) {
+                pcr_pt o;
+                o.x = ax; o.y = ay; o.z = az; o.id = p.id;
+                q[qi] = o;
+            }
+        }
+        cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
+        cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
+        cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
+    }
+    
+    WT_STAMP(0);
+    // per-query state across the passes (identical in the four lanes of a query after every merge)
+    bool open = qvalid;                         // not yet proven
+    const float gate2 = gated ? (float)max_d2 * (1.0f + 1e-6f) : INFINITY;   // rounded up: only ever used as an outer bound
+    float bound2 = gate2;                       // squared radius that provably holds the nearest neighbour (or the gate)
+    unsigned int cand_pos = POS_NONE;
+    if (use_prev && qvalid && !clamped) {
+        // ICP iterations after the first: res_pos still holds every query's neighbour of the PREVIOUS pass (the target
+        // never changes).  Its exact distance from the query's new position bounds the search ball at once, so the
+        // first box is the bounding box of tight balls instead of cells + 1 ring, and one pass proves almost every query.
+        const unsigned int pp = res_pos[qi];
+        if (pp != POS_NONE) {
+            const wt_xyz b = *reinterpret_cast<const wt_xyz*>(&g_pts[pp]);
+            const double dx = ax - b.x, dy = ay - b.y, dz = az - b.z;
+            const float up = (float)((dx * dx + dy * dy) + dz * dz) * (1.0f + 2e-7f) + 1e-37f;   // rounded up
+            if (up < bound2) { bound2 = up; cand_pos = pp; }
+        }
+    }
+    unsigned long long dbg_pairs = 0;
+    unsigned int dbg_passes = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < WT_PASSES; ++pass) {
+        const bool part = open && !clamped;
+        if (!__any(part)) break;
+        // ---- the cube every open query claims, in level-0 cell coordinates
+        int mn[3], mx[3];
+        {
+            const float rho = (cand_pos != POS_NONE) ? sqrtf(bound2) * (1.0f + 1e-6f) : fminf((float)gv.cell0 * (float)(1 << (2 * pass)), sqrtf(gate2));
+            // half-width in cells; the claim only steers the box (what is proven is decided against the box actually staged)
+            const double rc = fmin((double)rho * gv.inv_cell0, 262144.0);
+            // the query in level-0 cell units (clamped queries never take part)
+            const double tx = (ax - gv.lo[0]) * gv.inv_cell0, ty = (ay - gv.lo[1]) * gv.inv_cell0, tz = (az - gv.lo[2]) * gv.inv_cell0;
+            const int cmax = (int)PCR_COORD_MAX;
+            mn[0] = part ? max(0, min(cmax, (int)floor(tx - rc) + (int)PCR_COORD_BIAS)) : 0x7fffffff;
+            mx[0] = part ? max(0, min(cmax, (int)floor(tx + rc) + (int)PCR_COORD_BIAS)) : -1;
+            mn[1] = part ? max(0, min(cmax, (int)floor(ty - rc) + (int)PCR_COORD_BIAS)) : 0x7fffffff;
+            mx[1] = part ? max(0, min(cmax, (int)floor(ty + rc) + (int)PCR_COORD_BIAS)) : -1;
+            mn[2] = part ? max(0, min(cmax, (int)floor(tz - rc) + (int)PCR_COORD_BIAS)) : 0x7fffffff;
+            mx[2] = part ? max(0, min(cmax, (int)floor(tz + rc) + (int)PCR_COORD_BIAS)) : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int lo_k = row16_min(mn[k]), hi_k = row16_max(mx[k]);   // every row of 16 lanes
+            if (WT_Q == 32) {   // queries 16..31 sit in row 1
+                lo_k = min(__builtin_amdgcn_readlane(lo_k, 0), __builtin_amdgcn_readlane(lo_k, 16));
+                hi_k = max(__builtin_amdgcn_readlane(hi_k, 0), __builtin_amdgcn_readlane(hi_k, 16));
+            }
+            mn[k] = __builtin_amdgcn_readfirstlane(lo_k);
+            mx[k] = __builtin_amdgcn_readfirstlane(hi_k);
+        }
+        // finest level whose box has <= WT_MAXC cells and <= 64 blocks (wave-uniform: scalar registers)
+        int level = -1, blo0 = 0, blo1 = 0, blo2 = 0, d0 = 0, d1 = 0, d2 = 0;
+        const int n_levels = gv.levels;
+        for (int l = 0; l < n_levels; ++l) {   // all operands are wave-uniform 32-bit integers: scalar ALU
+            const int b0 = mn[0] >> (2 * l), b1 = mn[1] >> (2 * l), b2 = mn[2] >> (2 * l);
+            const int e0 = (mx[0] >> (2 * l)) - b0 + 1, e1 = (mx[1] >> (2 * l)) - b1 + 1, e2 = (mx[2] >> (2 * l)) - b2 + 1;
+            if (e0 > WT_MAXC || e1 > WT_MAXC || e2 > WT_MAXC || e0 * e1 > WT_MAXC || e0 * e1 * e2 > WT_MAXC) continue;
+            const int n0 = ((b0 + e0 - 1) >> 1) - (b0 >> 1) + 1, n1 = ((b1 + e1 - 1) >> 1) - (b1 >> 1) + 1, n2 = ((b2 + e2 - 1) >> 1) - (b2 >> 1) + 1;
+            if (n0 * n1 * n2 > 64) continue;
+            level = l; blo0 = b0; blo1 = b1; blo2 = b2; d0 = e0; d1 = e1; d2 = e2;
+            break;
+        }
+        level = __builtin_amdgcn_readfirstlane(level);
+        if (level < 0) break;
+        blo0 = __builtin_amdgcn_readfirstlane(blo0); blo1 = __builtin_amdgcn_readfirstlane(blo1); blo2 = __builtin_amdgcn_readfirstlane(blo2);
+        d0 = __builtin_amdgcn_readfirstlane(d0); d1 = __builtin_amdgcn_readfirstlane(d1); d2 = __builtin_amdgcn_readfirstlane(d2);
+        ++dbg_passes;
+        WT_STAMP(1);
+        // ---- directory: one 2x2x2 block per lane (<= 64 blocks by the level choice)
+        unsigned int ncell = 0;
+        {
+            const int lim = (int)(PCR_COORD_MAX >> (2 * level));
+            const int bx0 = blo0 >> 1, by0 = blo1 >> 1, bz0 = blo2 >> 1;
+            const int nb0 = ((blo0 + d0 - 1) >> 1) - bx0 + 1, nb1 = ((blo1 + d1 - 1) >> 1) - by0 + 1, nb2 = ((blo2 + d2 - 1) >> 1) - bz0 + 1;
+            const int nb01 = nb0 * nb1, nblk = nb01 * nb2;
+            pcr_block_slot e;
+            bool have = false;
+            int BX = 0, BY = 0, BZ = 0;
+            if (lane < nblk) {
+                // block index -> (ix, iy, iz) without an integer division (lane < 64: the float quotient is fixed up)
+                int iz = (int)((float)lane * (1.0f / (float)nb01));
+                iz -= (iz * nb01 > lane);
+                iz += ((iz + 1) * nb01 <= lane);
+                const int rem = lane - iz * nb01;
+                int iy = (int)((float)rem * (1.0f / (float)nb0));
+                iy -= (iy * nb0 > rem);
+                iy += ((iy + 1) * nb0 <= rem);
+                const int ix = rem - iy * nb0;
+                BX = bx0 + ix; BY = by0 + iy; BZ = bz0 + iz;
+                const int blim = lim >> 1;
+                if (BX >= 0 && BY >= 0 && BZ >= 0 && BX <= blim && BY <= blim && BZ <= blim)
+                    have = lookup_block(as_global(gv.btable[level]), gv.bmask[level], (unsigned int)BX, (unsigned int)BY, (unsigned int)BZ, &e);
+            }
+            // occupied children inside the box -> compact cell list (start, count) in LDS, in slot order
+            unsigned int run = have ? e.start : 0u;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                unsigned int cs = run, cn = have ? (unsigned int)e.cnt[ch] : 0u;
+                if (have && e.flags) {  // a child too large for 16 bits: ask the cell table
+                    unsigned int s2 = 0, e2 = 0;
+                    lookup_cell(as_global(gv.table[level]), gv.mask[level], (unsigned int)(2 * BX + (ch & 1)), (unsigned int)(2 * BY + ((ch >> 1) & 1)),
+                                (unsigned int)(2 * BZ + (ch >> 2)), &s2, &e2);
+                    cs = s2; cn = e2 - s2;
+                }
+                run += cn;
+                const int X = 2 * BX + (ch & 1) - blo0, Y = 2 * BY + ((ch >> 1) & 1) - blo1, Z = 2 * BZ + (ch >> 2) - blo2;
+                const bool in = have && cn > 0 && X >= 0 && Y >= 0 && Z >= 0 && X < d0 && Y < d1 && Z < d2;
+                const unsigned long long m = __ballot(in);
+                if (in) {
+                    const unsigned int slot = ncell + __popcll(m & ((1ull << lane) - 1ull));
+                    L->c_start[slot] = cs;
+                    L->c_off[slot] = cn;
+                }
+                ncell += __popcll(m);
+            }
+        }
+        wave_sync();
+        WT_STAMP(2);
+        // ---- exclusive prefix of the cell counts in slot order (<= WT_MAXC = 2 x 64 cells)
+        unsigned int total = 0;
+        {
+            unsigned int t0 = 0, t1 = 0;
+            const unsigned int c0 = (unsigned int)lane < ncell ? L->c_off[lane] : 0u;
+            const unsigned int c1 = (unsigned int)(lane + 64) < ncell ? L->c_off[lane + 64] : 0u;
+            const unsigned int p0 = wave_excl_scan_u32(c0, lane, &t0);
+            unsigned int p1 = 0;
+            if (ncell > 64) p1 = wave_excl_scan_u32(c1, lane, &t1);
+            if ((unsigned int)lane < ncell) L->c_off[lane] = p0;
+            if ((unsigned int)(lane + 64) < ncell) L->c_off[lane + 64] = t0 + p1;
+            total = t0 + t1;
+        }
+        wave_sync();
+        WT_STAMP(3);
+        if (total > pcap) continue;   // too many points to stage around this tile: a later pass has tighter balls, or the hard stage takes over
+        if (dbg) dbg_pairs += (unsigned long long)total * (unsigned long long)__popcll(__ballot(part && lane < WT_Q));
+        const float cellLf = (float)gv.cell0 * (float)(1 << (2 * level));
+        const double cellL = gv.cell0 * (double)(1ll << (2 * level));
+        const int blL = (int)(PCR_COORD_BIAS >> (2 * level));
+        const double ox = gv.lo[0] + ((double)(blo0 - blL) + 0.5 * d0) * cellL;
+        const double oy = gv.lo[1] + ((double)(blo1 - blL) + 0.5 * d1) * cellL;
+        const double oz = gv.lo[2] + ((double)(blo2 - blL) + 0.5 * d2) * cellL;
+        const float qxf = (float)(ax - ox), qyf = (float)(ay - oy), qzf = (float)(az - oz);
+        float fm = INFINITY, fs = INFINITY, s_in = INFINITY;
+        unsigned int bpos = POS_NONE;
+        if (total > 0) {
+            const f2 qx2 = {qxf, qxf}, qy2 = {qyf, qyf}, qz2 = {qzf, qzf};
+            const int slice = lane / WT_Q;
+            unsigned int carry = 0;  // owner cell of the last position of the previous round
+#pragma unroll 1
+            for (unsigned int base = 0; base < total; base += WT_PR) {
+                const unsigned int cnt = min(total - base, (unsigned int)WT_PR);
+                // owner cell of every staged position: mark the first position of each cell (slot ids increase with the
+                // position, cells are non-empty), then a running maximum over the positions
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) L->own[64 * c3 + lane] = 0;
+                wave_sync();
+                for (unsigned int c = lane; c < ncell; c += 64) {
+                    const unsigned int f = L->c_off[c];
+                    if (f >= base && f < base + cnt) L->own[f - base] = (unsigned short)c;
+                }
+                wave_sync();
+                unsigned int ow[3];
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) ow[c3] = (unsigned int)L->own[64 * c3 + lane];
+                unsigned int jj[3];
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    unsigned int v = max(wave_incl_scan_max(ow[c3]), carry);
+                    carry = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+                    const unsigned int k = 64 * c3 + lane;
+                    const unsigned int vv = k < cnt ? v : 0u;
+                    jj[c3] = L->c_start[vv] + (base + k - L->c_off[vv]);
+                }
+                // the (up to) three target records of this lane, requested back to back: one memory round trip per round
+                wt_xyz rec[3];
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3)
+                    if (64 * c3 + lane < cnt) rec[c3] = *reinterpret_cast<const wt_xyz*>(&g_pts[jj[c3]]);
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const unsigned int k = 64 * c3 + lane;
+                    if (k < cnt) {
+                        L->px[k] = (float)(rec[c3].x - ox); L->py[k] = (float)(rec[c3].y - oy); L->pz[k] = (float)(rec[c3].z - oz);
+                        L->ppos[k] = jj[c3];
+                    }
+                }
+                if (lane < 8) { L->px[cnt + lane] = 1e30f; L->py[cnt + lane] = 0.0f; L->pz[cnt + lane] = 0.0f; }  // pad the last group of 8
+                wave_sync();
+                WT_STAMP(4);
+                // filter: slice s takes groups s, s+4, ... of 8 staged points (see grid_tile_kernel for the arithmetic)
+                if (part) {
+                    int rk = -1;
+                    for (unsigned int k0 = slice * 8; k0 < cnt; k0 += 8 * (64 / WT_Q)) {
+                        f2 d[4];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const unsigned int k = k0 + 4 * u;
+                            const f4 bx4 = *reinterpret_cast<const f4*>(&L->px[k]);
+                            const f4 by4 = *reinterpret_cast<const f4*>(&L->py[k]);
+                            const f4 bz4 = *reinterpret_cast<const f4*>(&L->pz[k]);
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f2 bx = h ? f2{bx4.z, bx4.w} : f2{bx4.x, bx4.y};
+                                const f2 by = h ? f2{by4.z, by4.w} : f2{by4.x, by4.y};
+                                const f2 bz = h ? f2{bz4.z, bz4.w} : f2{bz4.x, bz4.y};
+                                const f2 dx = qx2 - bx, dy = qy2 - by, dz = qz2 - bz;
+                                f2 t = dx * dx;
+                                t = __builtin_elementwise_fma(dy, dy, t);
+                                d[2 * u + h] = __builtin_elementwise_fma(dz, dz, t);
+                            }
+                        }
+                        float m8 = fmin3(d[0].x, d[0].y, d[1].x);
+                        m8 = fmin3(m8, d[1].y, d[2].x);
+                        m8 = fmin3(m8, d[2].y, d[3].x);
+                        m8 = fmin3(m8, d[3].y, d[3].y);
+                        const bool lt = m8 < fm;
+                        fs = __builtin_amdgcn_fmed3f(m8, fm, fs);
+                        fm = __builtin_amdgcn_fmed3f(m8, fm, -INFINITY);
+                        rk = lt ? (int)k0 : rk;
+                    }
+                    if (rk >= 0) {
+                        float best = INFINITY, second = INFINITY;
+                        int bi = rk;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float ddx = qxf - L->px[rk + j], ddy = qyf - L->py[rk + j], ddz = qzf - L->pz[rk + j];
+                            const float dj = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx));
+                            if (dj < best) { second = best; best = dj; bi = rk + j; }
+                            else if (dj < second) second = dj;
+                        }
+                        bpos = L->ppos[bi];
+                        s_in = second;
+                    }
+                }
+                wave_sync();
+                WT_STAMP(5);
+            }
+            fs = fminf(fs, s_in);
+        }
+        // ---- merge the four candidate slices of every query
+#pragma unroll
+        for (int off = WT_Q; off < 64; off <<= 1) {
+            const float om = __shfl_xor(fm, off, 64), os = __shfl_xor(fs, off, 64);
+            const unsigned int op = __shfl_xor(bpos, off, 64);
+            fs = fminf(fmaxf(fm, om), fminf(fs, os));
+            if (om < fm) { fm = om; bpos = op; }
+        }
+        if (part) {
+            // binary32 with outward rounding throughout: U bounds the winner's true squared distance from above
+            float U = INFINITY;
+            bool ambiguous = false;
+            if (bpos != POS_NONE) {
+                // coordinate error of the filter: |local coordinate| <= R, binary32 conversion + subtraction
+                const float R = 0.5f * cellLf * (float)max(d0, max(d1, d2));
+                const float e = 8.0f * 5.9604644775390625e-08f * R * (1.0f + 1e-6f);
+                const float dhi = sqrtf(fm) * (1.0f + 2e-6f) + e;
+                U = (dhi + e) * (dhi + e) * (1.0f + 2e-6f);
+                ambiguous = fs <= U;
+            }
+            // distance from the query to the boundary of the staged box, in the filter's own local coordinates
+            // (error of a local coordinate <= e/8 * 2, covered by the slack)
+            float db = fminf(fminf(0.5f * d0 * cellLf - fabsf(qxf), 0.5f * d1 * cellLf - fabsf(qyf)), 0.5f * d2 * cellLf - fabsf(qzf));
+            db = fmaxf(db - cellLf * (float)max(d0, max(d1, d2)) * 4e-6f, 0.0f);
+            const float reach2 = fminf(U, bound2);   // the nearest neighbour (if within the gate) lies within this squared radius
+            if (!ambiguous && reach2 <= db * db * (1.0f - 2e-6f)) {
+                // proven: the filter's winner is the exact nearest neighbour, or nothing lies within the gate
+                open = false;
+                if (lane < WT_Q) {
+                    if (res_d2) {
+                        double dd = DBL_MAX;
+                        if (bpos != POS_NONE) {
+                            const pcr_pt bb = g_pts[bpos];
+                            dd = dist2(ax, ay, az, bb);   // exact, direct form (the nn1 API reports it)
+                        }
+                        res_d2[qi] = dd;
+                    }
+                    res_pos[qi] = bpos;
+                }
+            } else if (bpos != POS_NONE && U < bound2) {
+                bound2 = U;           // a real candidate: the next pass (or the hard stage) searches inside its ball
+                cand_pos = bpos;
+            }
+        }
+    }
+    WT_STAMP(6);
+    // ---- what is still open goes to the hard stage: one append per wave
+    const bool unres = open && lane < WT_Q;
+    const unsigned long long m = __ballot(unres);
+    if (m) {
+        const unsigned int n_unres = __popcll(m);
+        unsigned int base = 0;
+        const unsigned int hl = (blk * 4 + wave) % H_NLIST;
+        if (lane == 0) base = hl * hard_list_cap(nq) + atomicAdd(hard_count + H_CSTRIDE * hl, n_unres);
+        base = __shfl(base, 0, 64);
+        if (unres) {
+            work_item it;
+            it.ax = ax; it.ay = ay; it.az = az;
+            it.best_d2 = (clamped || cand_pos == POS_NONE) ? DBL_MAX : (double)bound2;
+            it.best_pos = clamped ? POS_NONE : cand_pos;
+            it.qi = (unsigned int)qi;
+            hard_list[base + __popcll(m & ((1ull << lane) - 1ull))] = it;
+        }
+    }
+    if (dbg && lane == 0) {
+        atomicAdd(&dbg[blockIdx.x * 4 + 1], dbg_pairs);
+        atomicAdd(&dbg[blockIdx.x * 4 + 2], (unsigned long long)dbg_passes);
+        atomicAdd(&dbg[blockIdx.x * 4 + 3], (unsigned long long)__popcll(m));
+        atomicMax(&dbg[blockIdx.x * 4 + 0], __builtin_amdgcn_s_memtime() - t_start);
+        WT_STAMP(7);
+        if (wave == 0)
+            for (int i = 0; i < 8; ++i) dbg[(1 << 16) + blockIdx.x * 8 + i] = t_ph[i];
     }
 }
 
@@ -909,7 +1364,7 @@ static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
 // Enqueues the search stages on `stream` over the `nq` records at `q` (a whole Morton-sorted cloud or a run of it);
 // leaves res_pos (and res_d2 when the scratch has it) on the device.  `st` != null: device-resident ICP loop.
 static int grid_search_enqueue(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, hipStream_t stream, const pcr_xform* x, int write_back,
-                               double max_d2, bool gated, bool mark, grid_scratch* sc, const pcr_icp_dev_state* st) {
+                               double max_d2, bool gated, bool mark, grid_scratch* sc, const pcr_icp_dev_state* st, bool use_prev = false) {
     const int nblocks = (int)((nq + TQ - 1) / TQ);
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
@@ -919,8 +1374,19 @@ static int grid_search_enqueue(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, in
     const int maxc = maxc_env > 0 && maxc_env <= T_MAXC ? maxc_env : T_MAXC;
     static const int pcap_env = getenv("PCR_TILE_PCAP") ? atoi(getenv("PCR_TILE_PCAP")) : 0;
     const unsigned int pcap = pcap_env > 0 ? (unsigned int)pcap_env : (nblocks > 8 * ctx->cu_count ? T_PCAP_LARGE : T_PCAP_SMALL);
-    hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), 0, stream, idx->view, q, (long long)nq, x ? *x : xi, (x || st) ? 1 : 0,
-                       write_back, max_d2, gated ? 1 : 0, xcd_remap, pcap, maxc, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug, st);
+    static const int old_tile = getenv("PCR_TILE_OLD") ? atoi(getenv("PCR_TILE_OLD")) : 0;
+    if (old_tile) {
+        hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), 0, stream, idx->view, q, (long long)nq, x ? *x : xi, (x || st) ? 1 : 0,
+                           write_back, max_d2, gated ? 1 : 0, xcd_remap, pcap, maxc, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug, st);
+    } else {
+        static const int wt_rounds_env = getenv("PCR_WT_ROUNDS") ? atoi(getenv("PCR_WT_ROUNDS")) : 0;
+        const unsigned int wpcap = (unsigned int)WT_PR * (wt_rounds_env > 0 ? wt_rounds_env : (nblocks > 8 * ctx->cu_count ? WT_ROUNDS_LARGE : WT_ROUNDS_SMALL));
+        if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)nblocks), stream);
+        const int wblocks = (int)((nq + 4 * WT_Q - 1) / (4 * WT_Q));
+        hipLaunchKernelGGL(grid_wtile_kernel, dim3(wblocks), dim3(256), 0, stream, (const pcr_grid_view*)idx->d_view, q, (long long)nq, x ? *x : xi, (x || st) ? 1 : 0,
+                           write_back, max_d2, gated ? 1 : 0, xcd_remap, wpcap, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug, st,
+                           use_prev ? 1 : 0);
+    }
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;
@@ -1078,6 +1544,7 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         h_st->t_last[i] = T0[4 * i + 3];
     }
     h_st->first = 1;
+    for (int i = 0; i < 9; ++i) h_st->V[i] = (i % 4 == 0) ? 1.0 : 0.0;
     pcr_icp_loop_args la;
     la.max_iter = params->max_iter; la.min_iter = params->min_iter;
     la.compat = params->mode == PCR_ICP_COMPAT_MAIN; la.r_metric = params->r_metric;
@@ -1089,16 +1556,23 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     // chunk schedule: what is known to run (min_iter) in one go, otherwise 2, 4, 8, ... (the reference's thresholds
     // usually stop after 1-3 iterations; a no-op pass costs three empty launches)
     int chunk = params->min_iter > 2 ? params->min_iter : 2;
+    if (ctx->profile) chunk = 1;   // the state must be read after every pass: a pass behind a stop would log empty kernels
     while (e == hipSuccess && rc == PCR_OK && enq < params->max_iter) {
         if (chunk > params->max_iter - enq) chunk = params->max_iter - enq;
         if (chunk > 64) chunk = 64;
         for (int c = 0; c < chunk && rc == PCR_OK; ++c) {
-            rc = grid_search_enqueue(ctx, idx, qc->d, nq, ctx->stream, nullptr, 1, params->max_d2, gated, false, &sc, d_st);
+            // from the second pass on, res_pos holds the previous pass's neighbours (same query order, same target)
+            static const bool no_prev = getenv("PCR_NO_PREV") != nullptr;
+            rc = grid_search_enqueue(ctx, idx, qc->d, nq, ctx->stream, nullptr, 1, params->max_d2, gated, ctx->profile, &sc, d_st, enq + c > 0 && !no_prev);
             if (rc) break;
+            pcr_prof_mark(ctx, 2);
             // after the write-back of the tile kernel the cloud already holds the transformed points
             hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, xi,
                                0, (const unsigned int*)sc.res_pos, params->max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
                                (double*)nullptr, sc.hard_count, d_st, la);
+            pcr_prof_mark(ctx, 3);
+            pcr_prof_mark(ctx, 4);
+            pcr_prof_finish(ctx);   // per-kernel HIP events (profiling only: one event sync per pass)
             ++launches;
         }
         enq += chunk;
@@ -1106,7 +1580,7 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         e = hipMemcpyAsync(h_st, d_st, sizeof(*h_st), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess || h_st->stop) break;
-        chunk *= 2;
+        if (!ctx->profile) chunk *= 2;
     }
     if (e == hipSuccess) e = hipGetLastError();
     grid_scratch_free(ctx, &sc);

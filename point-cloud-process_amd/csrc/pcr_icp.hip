@@ -127,7 +127,7 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
     PCR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     int rc = PCR_OK;
     static const bool host_loop_env = getenv("PCR_ICP_HOSTLOOP") != nullptr;
-    if (index->kind == PCR_INDEX_GRID && !ctx->profile && ctx->icp_lanes == 1 && !host_loop_env) {
+    if (index->kind == PCR_INDEX_GRID && ctx->icp_lanes == 1 && !host_loop_env) {
         // grid index: the whole loop runs on the device, the host only enqueues passes (pcr_grid_search.hip)
         rc = pcr_grid_icp_loop(ctx, index, source, params, T0, res);
     } else {
@@ -143,6 +143,7 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
             st.t_last[i] = T0[4 * i + 3];
         }
         st.first = 1;
+        for (int i = 0; i < 9; ++i) st.V[i] = (i % 4 == 0) ? 1.0 : 0.0;
         pcr_icp_loop_args la;
         la.max_iter = params->max_iter; la.min_iter = params->min_iter; la.compat = compat ? 1 : 0; la.r_metric = params->r_metric;
         la.r_thres = params->r_thres; la.t_thres = params->t_thres;

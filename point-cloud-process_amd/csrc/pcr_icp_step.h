@@ -42,7 +42,7 @@ __host__ __device__ inline void icp_step(pcr_icp_dev_state* st, const double* m,
         return;
     }
     double R[9], t[3], cost;
-    kabsch_from_moments(m, origin, R, t, &cost);
+    kabsch_from_moments(m, origin, R, t, &cost, st->V);   // warm start from the previous iteration's right singular vectors
     st->cost = cost;
     const int it = st->it;
     st->it = it + 1;

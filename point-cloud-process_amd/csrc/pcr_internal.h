@@ -74,6 +74,7 @@ struct pcr_index {
     pcr_block_slot* btables[PCR_MAX_LEVELS] = {nullptr};
     unsigned int bcaps[PCR_MAX_LEVELS] = {0};
     pcr_grid_view view;
+    pcr_grid_view* d_view = nullptr;  // device copy of `view`
     // BRUTE (f64 MFMA operand layout): tiles of 16 targets, 64 doubles per tile in lane order
     double* mfma_a = nullptr;   // [n_tiles][64]
     pcr_pt* plain = nullptr;    // targets in original order, centred copy not needed (exact recheck uses these)
@@ -172,6 +173,7 @@ struct __attribute__((aligned(16))) pcr_icp_dev_state {
     pcr_xform x;          // transform the NEXT pass applies = last solved increment (T_cur / T_ret of the host loop)
     double T_total[16];   // composed transform applied so far
     double R_last[9], t_last[3];
+    double V[9];          // right singular vectors of the last Procrustes solve (warm start of the next one); identity at first
     double cost, mean_d2;
     long long n_assoc;
     int it;               // Procrustes solves performed

@@ -8,37 +8,78 @@ namespace pcr {
 
 // One-sided Jacobi SVD of a 3x3 matrix (row-major): H = U diag(s) V^T.
 // Columns of U for zero singular values are completed to an orthonormal basis.
-__host__ __device__ inline void svd3(const double H[9], double U[9], double s[3], double V[9]) {
+template <int P, int Q>
+__host__ __device__ inline void svd3_rotate(double A[9], double V[9], double& off) {
+    const double alpha = (A[P] * A[P] + A[3 + P] * A[3 + P]) + A[6 + P] * A[6 + P];
+    const double beta = (A[Q] * A[Q] + A[3 + Q] * A[3 + Q]) + A[6 + Q] * A[6 + Q];
+    const double gamma = (A[P] * A[Q] + A[3 + P] * A[3 + Q]) + A[6 + P] * A[6 + Q];
+    if (gamma == 0.0) return;
+    const double ab = sqrt(alpha * beta);
+    if (fabs(gamma) <= 1e-17 * ab) return;
+    off = fmax(off, fabs(gamma) / ab);
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double ap = A[3 * i + P], aq = A[3 * i + Q];
+        A[3 * i + P] = c * ap - sn * aq;
+        A[3 * i + Q] = sn * ap + c * aq;
+        const double vp = V[3 * i + P], vq = V[3 * i + Q];
+        V[3 * i + P] = c * vp - sn * vq;
+        V[3 * i + Q] = sn * vp + c * vq;
+    }
+}
+
+// column B of U := cross product of the other two columns
+template <int B>
+__host__ __device__ inline void svd3_complete_one(double U[9]) {
+    constexpr int p = (B + 1) % 3, q = (B + 2) % 3;
+    const double c0 = U[3 * 1 + p] * U[3 * 2 + q] - U[3 * 2 + p] * U[3 * 1 + q];
+    const double c1 = U[3 * 2 + p] * U[3 * 0 + q] - U[3 * 0 + p] * U[3 * 2 + q];
+    const double c2 = U[3 * 0 + p] * U[3 * 1 + q] - U[3 * 1 + p] * U[3 * 0 + q];
+    U[B] = c0; U[3 + B] = c1; U[6 + B] = c2;
+}
+
+// rank <= 1: column G is the only usable one (or none is: have == false): build any orthonormal completion
+template <int G>
+__host__ __device__ inline void svd3_complete_two(double U[9], bool have) {
+    double u0[3] = {1, 0, 0};
+    if (have) { u0[0] = U[G]; u0[1] = U[3 + G]; u0[2] = U[6 + G]; }
+    const int ax = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+    const double e0 = ax == 0 ? 1.0 : 0.0, e1 = ax == 1 ? 1.0 : 0.0, e2 = ax == 2 ? 1.0 : 0.0;
+    double v1[3] = {u0[1] * e2 - u0[2] * e1, u0[2] * e0 - u0[0] * e2, u0[0] * e1 - u0[1] * e0};
+    const double n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
+    v1[0] /= n1; v1[1] /= n1; v1[2] /= n1;
+    const double v2[3] = {u0[1] * v1[2] - u0[2] * v1[1], u0[2] * v1[0] - u0[0] * v1[2], u0[0] * v1[1] - u0[1] * v1[0]};
+    // columns in the order G, then the remaining two ascending
+    constexpr int c1 = G == 0 ? 1 : 0, c2 = G == 2 ? 1 : 2;
+    U[G] = u0[0]; U[3 + G] = u0[1]; U[6 + G] = u0[2];
+    U[c1] = v1[0]; U[3 + c1] = v1[1]; U[6 + c1] = v1[2];
+    U[c2] = v2[0]; U[3 + c2] = v2[1]; U[6 + c2] = v2[2];
+}
+
+// V0 (optional): an orthogonal starting basis, e.g. the V of a nearby matrix (consecutive ICP iterations): the sweeps
+// then start from A = H V0, which is already close to orthogonal columns, and usually one or two sweeps remain.
+// Any orthogonal V0 yields a valid decomposition; R = U V^T does not depend on it beyond rounding.
+__host__ __device__ inline void svd3(const double H[9], double U[9], double s[3], double V[9], const double* V0 = nullptr) {
     double A[9];
-    for (int i = 0; i < 9; ++i) A[i] = H[i];
-    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (V0) {
+        for (int i = 0; i < 9; ++i) V[i] = V0[i];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) A[3 * i + j] = H[3 * i] * V0[j] + H[3 * i + 1] * V0[3 + j] + H[3 * i + 2] * V0[6 + j];
+    } else {
+        for (int i = 0; i < 9; ++i) A[i] = H[i];
+        for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    // the three column pairs are spelled out with constant indices: with a (p, q) loop the arrays are indexed dynamically
+    // and live in scratch memory on the device -- ~20 dependent memory round trips per rotation in the single thread that
+    // solves the ICP step
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0.0;
-        for (int p = 0; p < 2; ++p) {
-            for (int q = p + 1; q < 3; ++q) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int i = 0; i < 3; ++i) {
-                    alpha += A[3 * i + p] * A[3 * i + p];
-                    beta += A[3 * i + q] * A[3 * i + q];
-                    gamma += A[3 * i + p] * A[3 * i + q];
-                }
-                if (gamma == 0.0) continue;
-                double lim = 1e-17 * sqrt(alpha * beta);
-                if (fabs(gamma) <= lim) continue;
-                off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                for (int i = 0; i < 3; ++i) {
-                    double ap = A[3 * i + p], aq = A[3 * i + q];
-                    A[3 * i + p] = c * ap - sn * aq;
-                    A[3 * i + q] = sn * ap + c * aq;
-                    double vp = V[3 * i + p], vq = V[3 * i + q];
-                    V[3 * i + p] = c * vp - sn * vq;
-                    V[3 * i + q] = sn * vp + c * vq;
-                }
-            }
-        }
+        svd3_rotate<0, 1>(A, V, off);
+        svd3_rotate<0, 2>(A, V, off);
+        svd3_rotate<1, 2>(A, V, off);
         if (off < 1e-16) break;
     }
     double nrm[3];
@@ -54,35 +95,16 @@ __host__ __device__ inline void svd3(const double H[9], double U[9], double s[3]
         if (ok[j])
             for (int i = 0; i < 3; ++i) U[3 * i + j] = A[3 * i + j] / nrm[j];
     }
-    // complete U for (numerically) zero singular values
-    int nbad = (!ok[0]) + (!ok[1]) + (!ok[2]);
+    // complete U for (numerically) zero singular values (constant indices only: see svd3_rotate)
+    const int nbad = (!ok[0]) + (!ok[1]) + (!ok[2]);
     if (nbad == 1) {
-        int b = !ok[0] ? 0 : (!ok[1] ? 1 : 2);
-        int p = (b + 1) % 3, q = (b + 2) % 3;
-        double c0 = U[3 * 1 + p] * U[3 * 2 + q] - U[3 * 2 + p] * U[3 * 1 + q];
-        double c1 = U[3 * 2 + p] * U[3 * 0 + q] - U[3 * 0 + p] * U[3 * 2 + q];
-        double c2 = U[3 * 0 + p] * U[3 * 1 + q] - U[3 * 1 + p] * U[3 * 0 + q];
-        U[b] = c0; U[3 + b] = c1; U[6 + b] = c2;
+        if (!ok[0]) svd3_complete_one<0>(U);
+        else if (!ok[1]) svd3_complete_one<1>(U);
+        else svd3_complete_one<2>(U);
     } else if (nbad >= 2) {
-        // rank <= 1: build any orthonormal completion
-        double u0[3] = {1, 0, 0};
-        int g = -1;
-        for (int j = 0; j < 3; ++j) if (ok[j]) g = j;
-        if (g >= 0) { u0[0] = U[g]; u0[1] = U[3 + g]; u0[2] = U[6 + g]; }
-        int ax = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
-        double e[3] = {0, 0, 0};
-        e[ax] = 1.0;
-        double v1[3] = {u0[1] * e[2] - u0[2] * e[1], u0[2] * e[0] - u0[0] * e[2], u0[0] * e[1] - u0[1] * e[0]};
-        double n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
-        for (int i = 0; i < 3; ++i) v1[i] /= n1;
-        double v2[3] = {u0[1] * v1[2] - u0[2] * v1[1], u0[2] * v1[0] - u0[0] * v1[2], u0[0] * v1[1] - u0[1] * v1[0]};
-        int cols[3], nc = 0;
-        if (g < 0) g = 0;
-        cols[nc++] = g;
-        for (int j = 0; j < 3; ++j) if (j != g) cols[nc++] = j;
-        const double* vecs[3] = {u0, v1, v2};
-        for (int c = 0; c < 3; ++c)
-            for (int i = 0; i < 3; ++i) U[3 * i + cols[c]] = vecs[c][i];
+        if (ok[2]) svd3_complete_two<2>(U, true);
+        else if (ok[1]) svd3_complete_two<1>(U, true);
+        else svd3_complete_two<0>(U, ok[0]);
     }
 }
 
@@ -95,7 +117,8 @@ __host__ __device__ inline void mat3_mul(const double A[9], const double B[9], d
 //   m = {K, Sa[3], Sb[3], Sba[9] (b_i a_j), Saa, Sbb}
 // R = U V^T of H = sum (b-bbar)(a-abar)^T (no reflection fix, like Registration/main.py:137-139),
 // t = bbar - R abar, cost = ||B - (R A + t)||_F (main.py:140-141).
-__host__ __device__ inline void kabsch_from_moments(const double m[18], const double origin[3], double R[9], double t[3], double* cost) {
+__host__ __device__ inline void kabsch_from_moments(const double m[18], const double origin[3], double R[9], double t[3], double* cost,
+                                                    double* V_io = nullptr) {
     const double K = m[0];
     double abar[3] = {m[1] / K, m[2] / K, m[3] / K};
     double bbar[3] = {m[4] / K, m[5] / K, m[6] / K};
@@ -103,7 +126,9 @@ __host__ __device__ inline void kabsch_from_moments(const double m[18], const do
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) H[3 * i + j] = m[7 + 3 * i + j] - K * bbar[i] * abar[j];
     double U[9], s[3], V[9];
-    svd3(H, U, s, V);
+    svd3(H, U, s, V, V_io);
+    if (V_io)
+        for (int i = 0; i < 9; ++i) V_io[i] = V[i];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) R[3 * i + j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + U[3 * i + 2] * V[3 * j + 2];
     // means in world coordinates
