@@ -8,18 +8,29 @@ namespace pcr {
 
 // One-sided Jacobi SVD of a 3x3 matrix (row-major): H = U diag(s) V^T.
 // Columns of U for zero singular values are completed to an orthonormal basis.
+// One Jacobi rotation of columns P, Q.  Written for the single device thread that solves the ICP step: binary64
+// divisions and square roots are ~30-instruction dependent sequences there, so the rotation uses one sqrt, one
+// division and one reciprocal sqrt (the textbook zeta / t / c form needs three divisions and three square roots),
+// and the convergence tests compare squares instead of dividing.
 template <int P, int Q>
-__host__ __device__ inline void svd3_rotate(double A[9], double V[9], double& off) {
+__host__ __device__ inline void svd3_rotate(double A[9], double V[9], bool& rotated) {
     const double alpha = (A[P] * A[P] + A[3 + P] * A[3 + P]) + A[6 + P] * A[6 + P];
     const double beta = (A[Q] * A[Q] + A[3 + Q] * A[3 + Q]) + A[6 + Q] * A[6 + Q];
     const double gamma = (A[P] * A[Q] + A[3 + P] * A[3 + Q]) + A[6 + P] * A[6 + Q];
     if (gamma == 0.0) return;
-    const double ab = sqrt(alpha * beta);
-    if (fabs(gamma) <= 1e-17 * ab) return;
-    off = fmax(off, fabs(gamma) / ab);
-    const double zeta = (beta - alpha) / (2.0 * gamma);
-    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+    const double ab = alpha * beta, g2 = gamma * gamma;
+    if (g2 <= 1e-34 * ab) return;           // |gamma| <= 1e-17 sqrt(alpha beta): orthogonal to working precision
+    if (g2 >= 1e-32 * ab) rotated = true;   // |gamma| / sqrt(alpha beta) >= 1e-16: another sweep is needed
+    // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (beta - alpha) / (2 gamma), scaled by |2 gamma|
+    const double d = beta - alpha, g = 2.0 * fabs(gamma);
+    const bool pos = (d == 0.0) || ((d > 0.0) == (gamma > 0.0));
+    const double t = (pos ? g : -g) / (fabs(d) + sqrt(d * d + g * g));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double c = rsqrt(1.0 + t * t);
+#else
+    const double c = 1.0 / sqrt(1.0 + t * t);
+#endif
+    const double sn = c * t;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double ap = A[3 * i + P], aq = A[3 * i + Q];
@@ -76,11 +87,11 @@ __host__ __device__ inline void svd3(const double H[9], double U[9], double s[3]
     // and live in scratch memory on the device -- ~20 dependent memory round trips per rotation in the single thread that
     // solves the ICP step
     for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0;
-        svd3_rotate<0, 1>(A, V, off);
-        svd3_rotate<0, 2>(A, V, off);
-        svd3_rotate<1, 2>(A, V, off);
-        if (off < 1e-16) break;
+        bool rotated = false;
+        svd3_rotate<0, 1>(A, V, rotated);
+        svd3_rotate<0, 2>(A, V, rotated);
+        svd3_rotate<1, 2>(A, V, rotated);
+        if (!rotated) break;
     }
     double nrm[3];
     double nmax = 0;
@@ -92,8 +103,10 @@ __host__ __device__ inline void svd3(const double H[9], double U[9], double s[3]
     for (int j = 0; j < 3; ++j) {
         s[j] = nrm[j];
         ok[j] = nrm[j] > 1e-300 && nrm[j] > 1e-15 * nmax;
-        if (ok[j])
-            for (int i = 0; i < 3; ++i) U[3 * i + j] = A[3 * i + j] / nrm[j];
+        if (ok[j]) {
+            const double inv = 1.0 / nrm[j];
+            for (int i = 0; i < 3; ++i) U[3 * i + j] = A[3 * i + j] * inv;
+        }
     }
     // complete U for (numerically) zero singular values (constant indices only: see svd3_rotate)
     const int nbad = (!ok[0]) + (!ok[1]) + (!ok[2]);
@@ -119,9 +132,9 @@ __host__ __device__ inline void mat3_mul(const double A[9], const double B[9], d
 // t = bbar - R abar, cost = ||B - (R A + t)||_F (main.py:140-141).
 __host__ __device__ inline void kabsch_from_moments(const double m[18], const double origin[3], double R[9], double t[3], double* cost,
                                                     double* V_io = nullptr) {
-    const double K = m[0];
-    double abar[3] = {m[1] / K, m[2] / K, m[3] / K};
-    double bbar[3] = {m[4] / K, m[5] / K, m[6] / K};
+    const double K = m[0], invK = 1.0 / K;
+    double abar[3] = {m[1] * invK, m[2] * invK, m[3] * invK};
+    double bbar[3] = {m[4] * invK, m[5] * invK, m[6] * invK};
     double H[9];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) H[3 * i + j] = m[7 + 3 * i + j] - K * bbar[i] * abar[j];
