@@ -221,11 +221,40 @@ def execute_global_registration(source_down, target_down, source_fpfh, target_fp
         source_down, target_down, source_fpfh, target_fpfh, True, voxel_size * 1.5, 3, 0.9, True, 100000, 0.999, seed=seed, ctx=ctx)
 
 
-def ransac_init(src_cloud, tgt_cloud, voxel_size=2.0, seed=0, ctx=None):
-    """icp_template.py:56-110 -> (R (3,3), t (3,1)): detection = voxel down-sampling, description = FPFH,
-    correspondence = mutual nearest features, then RANSAC with procrustes_transformation on 3 samples."""
+def ransac_init(src_cloud, tgt_cloud, voxel_size=2.0, seed=0, ctx=None, detector="voxel", iss_radius=None, iss_count=400,
+                return_info=False):
+    """icp_template.py:56-110 -> (R (3,3), t (3,1)): feature DETECTION, feature DESCRIPTION (FPFH, 33-d),
+    correspondence = mutual nearest features, then RANSAC with procrustes_transformation on 3 samples.
+
+    detector="voxel": every point of the voxel_size down-sampled cloud is a feature point (what main.py:33-84 does).
+    detector="iss":   the template's own plan (icp_template.py:56-71 "feature detection"): ISS keypoints
+                      (Keypoint_detection_ISS/ISS.py:35-73 on the GPU, pcr_iss) of the down-sampled cloud, at most
+                      iss_count + 1 per cloud; descriptors are computed on the whole down-sampled cloud (their support) and
+                      only the keypoints' rows are matched and sampled by RANSAC.
+    """
     s_down, s_f = preprocess_point_cloud(src_cloud, voxel_size, ctx=ctx)
     t_down, t_f = preprocess_point_cloud(tgt_cloud, voxel_size, ctx=ctx)
-    res = execute_global_registration(s_down, t_down, s_f, t_f, voxel_size, seed=seed, ctx=ctx)
+    info = {"detector": detector, "n_src": len(s_down.points), "n_tgt": len(t_down.points)}
+    if detector == "iss":
+        from .iss import iss_keypoints
+
+        r = float(iss_radius) if iss_radius else 2.5 * voxel_size
+        ks = np.asarray(iss_keypoints(s_down.points, radius=r, non_max_radius=r, iss_count=iss_count, ctx=ctx), dtype=np.int64)
+        kt = np.asarray(iss_keypoints(t_down.points, radius=r, non_max_radius=r, iss_count=iss_count, ctx=ctx), dtype=np.int64)
+        info.update(n_src_keypoints=len(ks), n_tgt_keypoints=len(kt), iss_radius=r)
+        if len(ks) < 3 or len(kt) < 3:
+            raise ValueError(f"ISS found {len(ks)} / {len(kt)} keypoints: need at least 3 per cloud (lower the eigenvalue-ratio "
+                             "thresholds, change iss_radius, or use detector='voxel')")
+        s_kp, t_kp = PointCloud(np.asarray(s_down.points)[ks]), PointCloud(np.asarray(t_down.points)[kt])
+        s_kf, t_kf = Feature(np.asarray(s_f.data)[:, ks]), Feature(np.asarray(t_f.data)[:, kt])
+        res = execute_global_registration(s_kp, t_kp, s_kf, t_kf, voxel_size, seed=seed, ctx=ctx)
+    elif detector == "voxel":
+        res = execute_global_registration(s_down, t_down, s_f, t_f, voxel_size, seed=seed, ctx=ctx)
+    else:
+        raise ValueError("detector must be 'voxel' or 'iss'")
     T = res.transformation
-    return T[:3, :3].copy(), T[:3, 3].reshape(3, 1).copy()
+    R, t = T[:3, :3].copy(), T[:3, 3].reshape(3, 1).copy()
+    if return_info:
+        info.update(fitness=res.fitness, inlier_rmse=res.inlier_rmse, ransac=res.info)
+        return R, t, info
+    return R, t

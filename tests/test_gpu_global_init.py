@@ -128,6 +128,14 @@ def test_global_registration_then_icp_end_to_end(pcp, syn):
     assert R.shape == (3, 3) and t.shape == (3, 1) and np.allclose(R, res.transformation[:3, :3])
     homo2, _ = pcp.ICP(pcp.PointCloud(src), pcp.PointCloud(tgt), init="ransac")      # icp_template.py:145-152 (init_use_ransac)
     assert np.linalg.norm(homo2[:3, 3] - T_true[:3, 3]) < 0.5
+    # the template's own detector (icp_template.py:56-71): ISS keypoints as the feature points, same pipeline behind it
+    R3, t3, info = pcp.ransac_init(pcp.PointCloud(src), pcp.PointCloud(tgt), seed=1, detector="iss", iss_count=300, return_info=True)
+    assert 3 <= info["n_src_keypoints"] < info["n_src"]
+    T3 = np.eye(4)
+    T3[:3, :3], T3[:3, 3] = R3, t3[:, 0]
+    homo3, _ = pcp.ICP(pcp.PointCloud(src), pcp.PointCloud(tgt), init=T3)
+    assert np.abs(homo3[:3, :3] - T_true[:3, :3]).max() < 0.01 and np.linalg.norm(homo3[:3, 3] - T_true[:3, 3]) < 0.5
+    assert pcp.is_registration_successful(homo3, T_true)[0]
 
 
 def test_dataset_driver_with_global_init(pcp, syn, tmp_path):
