@@ -102,8 +102,11 @@ def test_fused_moments_match_oracle(pcp, oracle, syn, kind):
 def test_icp_compat_matches_reference_goldens(pcp, kind, capsys):
     """icp_point2point vs the outputs of the reference's own Registration/main.py:icp_point2point."""
     g = load_golden("icp_compat.npz")
-    for tag in g["cases"]:
+    big = load_golden("icp_compat_big.npz")     # SURVEY 8c G3 at N = 20 000 (the largest size the literal reference can run)
+    for tag in list(g["cases"]) + list(big["cases"]):
         tag = str(tag)
+        if tag in big.files or f"{tag}_src" in big.files:
+            g = big
         src = pcp.PointCloud(g[f"{tag}_src"])
         T, info = pcp.icp_point2point(src, g[f"{tag}_tgt"], g[f"{tag}_T0"], nn=kind, return_info=True)
         assert info["iters"] == int(g[f"{tag}_iters"][0]), tag

@@ -76,14 +76,17 @@ def test_knn_and_radius_match_reference_trees(pcp):
             for k in (1, 8):
                 for tree, fn, root in (("kd", pcp.kdtree_knn_search, kroot), ("oct", pcp.octree_knn_search, oroot)):
                     rs = pcp.KNNResultSet(capacity=k)
-                    fn(root, db, rs, q)
+                    ret = fn(root, db, rs, q)
+                    # the searches' boolean return (kdtree.py: always False; octree.py:187,212,...: "ball inside the octant")
+                    assert bool(ret) == bool(g[f"{name}_{tree}_knn{k}_ret"][qi]), (name, tree, k, qi)
                     assert [x.index for x in rs.dist_index_list] == g[f"{name}_{tree}_knn{k}_idx"][qi].tolist(), (name, tree, k, qi)
                     assert np.allclose([x.distance for x in rs.dist_index_list], g[f"{name}_{tree}_knn{k}_dist"][qi], rtol=1e-14, atol=0)
             for rad in rads:
                 for tree, fn, root in (("kd", pcp.kdtree_radius_search, kroot), ("oct", pcp.octree_radius_search, oroot),
                                        ("octfast", pcp.octree_radius_search_fast, oroot)):
                     rs = pcp.RadiusNNResultSet(radius=rad)
-                    fn(root, db, rs, q)
+                    ret = fn(root, db, rs, q)
+                    assert bool(ret) == bool(g[f"{name}_{tree}_rad{rad}_q{qi}_ret"][0]), (name, tree, rad, qi)
                     lst = sorted(rs.dist_index_list)
                     assert [x.index for x in lst] == g[f"{name}_{tree}_rad{rad}_q{qi}_idx"].tolist(), (name, tree, rad, qi)
                     assert rs.count == int(g[f"{name}_{tree}_rad{rad}_q{qi}_count"][0])
