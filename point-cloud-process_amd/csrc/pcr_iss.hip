@@ -86,7 +86,9 @@ __device__ static inline void sym3_eigenvalues(double a00, double a01, double a0
 }
 
 __global__ void __launch_bounds__(256) iss_cov_kernel(pcr_grid_view gv, long long n, double radius, const int* __restrict__ counts,
-                                                      double* __restrict__ lambdas /* by row id, (n,3) */) {
+                                                      double* __restrict__ lambdas /* by row id, (n,3) */, double gamma21, double gamma32,
+                                                      int* __restrict__ cand /* row ids passing the ratio tests, any order */,
+                                                      unsigned int* __restrict__ cand_count) {
     const int gl = threadIdx.x % IG;
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / IG;
     if (i >= n) return;
@@ -117,7 +119,15 @@ __global__ void __launch_bounds__(256) iss_cov_kernel(pcr_grid_view gv, long lon
         lambdas[3 * p.id + 0] = ev[0];
         lambdas[3 * p.id + 1] = ev[1];
         lambdas[3 * p.id + 2] = ev[2];
+        // ISS.py:55-57: candidate when both eigenvalue ratios pass (NaN ratios of degenerate neighbourhoods fail, like the
+        // reference's comparisons do); the host orders the (unordered) list, so the append order does not matter
+        if (cand && ev[1] / ev[0] < gamma21 && ev[2] / ev[1] < gamma32) cand[atomicAdd(cand_count, 1u)] = (int)p.id;
     }
+}
+
+__global__ void iss_gather_kernel(const pcr_pt* __restrict__ rows, const int* __restrict__ ids, int m, pcr_pt* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) out[j] = rows[ids[j]];
 }
 
 extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, double gamma21, double gamma32, double nms_radius,
@@ -136,47 +146,84 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
     if ((rc = pcr_dev_alloc(ctx, sizeof(int) * n, (void**)&d_counts))) return rc;
     if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 3 * n, (void**)&d_lam))) return rc;
     const unsigned grid = (unsigned)((n * IG + 255) / 256);
+    const bool want_kp = keypoints_out && n_keypoints_out;
+    int* d_cand = nullptr;
+    unsigned int* d_cand_count = ctx->d_counters + 124;
+    if (want_kp) {
+        if ((rc = pcr_dev_alloc(ctx, sizeof(int) * n, (void**)&d_cand))) return rc;
+        PCR_HIP(ctx, hipMemsetAsync(d_cand_count, 0, sizeof(unsigned int), ctx->stream));
+    }
     hipLaunchKernelGGL(iss_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, radius, d_counts);
-    hipLaunchKernelGGL(iss_cov_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, radius, (const int*)d_counts, d_lam);
+    hipLaunchKernelGGL(iss_cov_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, radius, (const int*)d_counts, d_lam, gamma21,
+                       gamma32, d_cand, d_cand_count);
     PCR_HIP(ctx, hipGetLastError());
     PCR_HIP(ctx, hipMemcpyAsync(lambdas_out, d_lam, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<int32_t> counts_host;
-    int32_t* cdst = counts_out;
-    if (!cdst) { counts_host.resize(n); cdst = counts_host.data(); }
-    PCR_HIP(ctx, hipMemcpyAsync(cdst, d_counts, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts_out) PCR_HIP(ctx, hipMemcpyAsync(counts_out, d_counts, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned int n_cand = 0;
+    if (want_kp) PCR_HIP(ctx, hipMemcpyAsync(&n_cand, d_cand_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pcr_dev_free(ctx, d_counts, sizeof(int) * n);
     pcr_dev_free(ctx, d_lam, sizeof(double) * 3 * n);
     rc = PCR_OK;
-    if (keypoints_out && n_keypoints_out) {
-        // candidates (ISS.py:55-57), sorted by lambda3 descending, stable (ISS.py:59)
-        std::vector<int> cand;
-        for (int64_t i = 0; i < n; ++i) {
-            const double l1 = lambdas_out[3 * i], l2 = lambdas_out[3 * i + 1], l3 = lambdas_out[3 * i + 2];
-            if (l2 / l1 < gamma21 && l3 / l2 < gamma32) cand.push_back((int)i);
+    if (want_kp) {
+        // Non-maximum suppression (ISS.py:59-73).  The reference walks the candidates in descending lambda_3 (stable: ties
+        // in input order) and, for each one still alive, keeps it and removes everything within nms_radius of it.  A
+        // candidate is therefore dropped exactly when an ALREADY KEPT keypoint lies within nms_radius: at most
+        // max_keypoints + 1 distance checks per candidate on the host, no radius queries; and only the head of the order is
+        // ever visited, so the candidates sit in a heap instead of being sorted.
+        std::vector<int> cand(n_cand);
+        if (n_cand) {
+            PCR_HIP(ctx, hipMemcpyAsync(cand.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return lambdas_out[3 * a + 2] > lambdas_out[3 * b + 2]; });
-        std::vector<char> alive(n, 0);
-        for (int c : cand) alive[c] = 1;
-        // point coordinates by row id for the NMS queries
-        std::vector<double> xyz(3 * n);
-        rc = pcr_cloud_download_f64(ctx, cloud, xyz.data());
+        auto later = [&](int a, int b) {  // heap order: a comes AFTER b
+            const double la = lambdas_out[3 * (size_t)a + 2], lb = lambdas_out[3 * (size_t)b + 2];
+            return la < lb || (la == lb && a > b);
+        };
+        std::make_heap(cand.begin(), cand.end(), later);
+        // coordinates of the visited candidates only: fetched in small batches by row id
+        pcr_pt *d_rows = nullptr, *d_batch = nullptr;
+        int* d_ids = nullptr;
+        constexpr size_t BATCH = 256;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&d_rows)) == PCR_OK) rc = pcr_cloud_rows(ctx, cloud, d_rows);
+        if (rc == PCR_OK) rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * BATCH, (void**)&d_batch);
+        if (rc == PCR_OK) rc = pcr_dev_alloc(ctx, sizeof(int) * BATCH, (void**)&d_ids);
+        std::vector<pcr_pt> kept;
         int taken = 0;
-        for (size_t ci = 0; ci < cand.size() && rc == PCR_OK; ++ci) {
-            const int id = cand[ci];
-            if (!alive[id]) continue;
-            keypoints_out[taken++] = id;
-            int64_t cnt = 0, offs[2] = {0, 0};
-            rc = pcr_radius(ctx, idx, &xyz[3 * (size_t)id], 1, nms_radius, &cnt, nullptr, nullptr, nullptr);
-            if (rc) break;
-            offs[1] = cnt;
-            std::vector<int32_t> nb((size_t)cnt + 1);
-            std::vector<double> nd((size_t)cnt + 1);
-            rc = pcr_radius(ctx, idx, &xyz[3 * (size_t)id], 1, nms_radius, nullptr, offs, nb.data(), nd.data());
-            if (rc) break;
-            for (int64_t j = 0; j < cnt; ++j) alive[nb[(size_t)j]] = 0;
-            if (taken > max_keypoints) break;  // ISS.py:72-73: stops once MORE than iss_count were taken
+        size_t heap_n = cand.size();
+        while (rc == PCR_OK && heap_n > 0) {
+            // pop the next batch of candidates in order and read their records with one copy each (they are few)
+            const size_t batch = std::min<size_t>(heap_n, BATCH);
+            std::vector<int> ids(batch);
+            for (size_t j = 0; j < batch; ++j) {
+                std::pop_heap(cand.begin(), cand.begin() + heap_n, later);
+                ids[j] = cand[--heap_n];
+            }
+            std::vector<pcr_pt> recs(batch);
+            PCR_HIP(ctx, hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(iss_gather_kernel, dim3(1), dim3((unsigned)BATCH), 0, ctx->stream, (const pcr_pt*)d_rows, (const int*)d_ids, (int)batch, d_batch);
+            PCR_HIP(ctx, hipMemcpyAsync(recs.data(), d_batch, sizeof(pcr_pt) * batch, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            bool done = false;
+            for (size_t j = 0; j < batch && !done; ++j) {
+                const pcr_pt& c = recs[j];
+                bool alive = true;
+                for (const pcr_pt& k : kept) {
+                    const double dx = k.x - c.x, dy = k.y - c.y, dz = k.z - c.z;
+                    const double d = sqrt((dx * dx + dy * dy) + dz * dz);   // the expression of the radius query (pcr_knn.hip)
+                    if (!(d > nms_radius)) { alive = false; break; }
+                }
+                if (!alive) continue;
+                kept.push_back(c);
+                keypoints_out[taken++] = ids[j];
+                if (taken > max_keypoints) done = true;  // ISS.py:72-73: stops once MORE than iss_count were taken
+            }
+            if (done) break;
         }
+        if (d_rows) pcr_dev_free(ctx, d_rows, sizeof(pcr_pt) * n);
+        if (d_batch) pcr_dev_free(ctx, d_batch, sizeof(pcr_pt) * BATCH);
+        if (d_ids) pcr_dev_free(ctx, d_ids, sizeof(int) * BATCH);
+        pcr_dev_free(ctx, d_cand, sizeof(int) * n);
         *n_keypoints_out = taken;
     }
     pcr_index_free(ctx, idx);
