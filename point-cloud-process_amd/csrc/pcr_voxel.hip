@@ -10,8 +10,8 @@
 //     is never emitted: output rows = occupied voxels - 1 (voxel_filter.py:42-51);
 //   * centroid = np.mean over the group = NumPy's pairwise summation (8 accumulators,
 //     blocks of 128) divided by the count -- restated here so the result is bitwise equal.
-// Pipeline on the device: bbox -> keys -> radix sort (key bits, index) -> group heads
-// (flag + exclusive scan) -> one thread per emitted voxel.
+// Pipeline on the device: bbox -> keys -> radix sort of (integer key, index) over the occupied key bits only ->
+// group heads (one rocprim::select with a computed flag) -> one thread per emitted voxel; one host sync at the end.
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -50,24 +50,15 @@ __global__ void voxel_keys_kernel(const pcr_pt* __restrict__ pts, long long n, d
     if (h_out) h_out[p.id] = h;
     if (key_bits) {
         // records may be device-reordered: sort position = row id, so that ties keep INPUT order
-        key_bits[p.id] = (unsigned long long)__double_as_longlong(h);  // h >= 0: bit pattern is monotone
+        key_bits[p.id] = (unsigned long long)h;  // h is a non-negative integer below 2^53: exact, and only its low bits need sorting
         vals[p.id] = (unsigned int)i;
     }
 }
 
-__global__ void voxel_heads_kernel(const unsigned long long* __restrict__ keys, long long n, unsigned int* __restrict__ flags) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-}
-
-__global__ void voxel_scatter_heads_kernel(const unsigned int* __restrict__ flags, const unsigned int* __restrict__ pos, long long n,
-                                           unsigned int* __restrict__ heads, unsigned int* __restrict__ n_groups) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flags[i]) heads[pos[i]] = (unsigned int)i;
-    if (i == n - 1) *n_groups = pos[i] + flags[i];
-}
+struct head_flag {  // position i starts a group of equal keys
+    const unsigned long long* keys;
+    __host__ __device__ bool operator()(unsigned int i) const { return i == 0u || keys[i] != keys[i - 1u]; }
+};
 
 // NumPy pairwise_sum over a[k] = coord(pts[perm[start + k]]), k in [0, n)
 struct coord_view {
@@ -210,7 +201,7 @@ static int voxel_prepare(pcr_ctx* ctx, const pcr_cloud* c, double leaf, double* 
     const int block = 256;
     const int grid_n = (int)((n + block - 1) / block);
     unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
-    unsigned int *d_vals = nullptr, *d_flags = nullptr, *d_pos = nullptr;
+    unsigned int* d_vals = nullptr;
     if (need_groups) {
         if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys))) return rc;
         if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys2))) return rc;
@@ -221,32 +212,46 @@ static int voxel_prepare(pcr_ctx* ctx, const pcr_cloud* c, double leaf, double* 
                        leaf, w->D[0], w->D[1], h_out_dev, d_keys, d_vals);
     PCR_HIP(ctx, hipGetLastError());
     if (!need_groups) return PCR_OK;
-    // keys are integral-valued doubles < 2^53: their bit patterns need at most 63 bits
+    // keys are non-negative integers bounded by the grid: sort only the bits they can occupy (a KITTI scan at 0.2 m needs
+    // 25 of the 64: half the radix passes)
+    int end_bit = 63;
+    {
+        double bound = 0.0;
+        if (open3d_binning) {
+            bound = w->D[0] * w->D[1] * w->D[2];
+        } else {
+            const double Hx = floor((w->mx[0] - w->mn[0]) / leaf), Hy = floor((w->mx[1] - w->mn[1]) / leaf), Hz = floor((w->mx[2] - w->mn[2]) / leaf);
+            bound = (Hx + Hy * w->D[0]) + (Hz * w->D[0]) * w->D[1];
+        }
+        if (bound >= 0.0 && bound < 4503599627370496.0) {  // 2^52
+            unsigned long long b = (unsigned long long)bound + 1ull;
+            end_bit = 1;
+            while ((b >> end_bit) != 0ull) ++end_bit;
+        }
+    }
     size_t temp_bytes = 0;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, w->perm, (size_t)n, 0, 63, ctx->stream));
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, w->perm, (size_t)n, 0, end_bit, ctx->stream));
     void* d_temp = nullptr;
     if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, w->perm, (size_t)n, 0, 63, ctx->stream));
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_flags))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_pos))) return rc;
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, w->perm, (size_t)n, 0, end_bit, ctx->stream));
     if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (n + 1), (void**)&w->heads))) return rc;
     w->n_groups = ctx->d_counters + 48;
-    hipLaunchKernelGGL(voxel_heads_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const unsigned long long*)d_keys2, n, d_flags);
+    // group heads = positions whose key differs from the previous one: one fused flag + scan + scatter (rocprim::select
+    // over a counting iterator with a computed flag), instead of a flag kernel, a scan and a scatter
+    const head_flag flag_op{d_keys2};
+    auto positions = rocprim::counting_iterator<unsigned int>(0u);
+    auto flags = rocprim::make_transform_iterator(positions, flag_op);
     size_t temp2 = 0;
-    PCR_HIP(ctx, rocprim::exclusive_scan(nullptr, temp2, d_flags, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), ctx->stream));
+    PCR_HIP(ctx, rocprim::select(nullptr, temp2, positions, flags, w->heads, w->n_groups, (size_t)n, ctx->stream));
     void* d_temp2 = nullptr;
     if ((rc = pcr_dev_alloc(ctx, temp2, &d_temp2))) return rc;
-    PCR_HIP(ctx, rocprim::exclusive_scan(d_temp2, temp2, d_flags, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), ctx->stream));
-    hipLaunchKernelGGL(voxel_scatter_heads_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const unsigned int*)d_flags,
-                       (const unsigned int*)d_pos, n, w->heads, w->n_groups);
+    PCR_HIP(ctx, rocprim::select(d_temp2, temp2, positions, flags, w->heads, w->n_groups, (size_t)n, ctx->stream));
     PCR_HIP(ctx, hipGetLastError());
     pcr_dev_free(ctx, d_temp, temp_bytes);
     pcr_dev_free(ctx, d_temp2, temp2);
     pcr_dev_free(ctx, d_keys, sizeof(unsigned long long) * n);
     pcr_dev_free(ctx, d_keys2, sizeof(unsigned long long) * n);
     pcr_dev_free(ctx, d_vals, sizeof(unsigned int) * n);
-    pcr_dev_free(ctx, d_flags, sizeof(unsigned int) * n);
-    pcr_dev_free(ctx, d_pos, sizeof(unsigned int) * n);
     return PCR_OK;
 }
 
@@ -285,17 +290,19 @@ static int voxel_filter_impl(pcr_ctx* ctx, const pcr_cloud* in, double leaf, int
     voxel_work w;
     int rc = voxel_prepare(ctx, in, leaf, nullptr, true, &w, mode == 2);
     if (rc) { voxel_release(ctx, &w); return rc; }
-    unsigned int ng = 0;
-    PCR_HIP(ctx, hipMemcpyAsync(&ng, w.n_groups, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t rows = mode == 2 ? (int64_t)ng : (ng > 0 ? (int64_t)ng - 1 : 0);
-    if (rows > 0) {
+    // the number of groups is only known on the device: launch for the upper bound (threads past the last emitted voxel
+    // leave at once) and read the count once everything is queued -- no host round trip in the middle of the chain
+    {
         const int block = 128;
-        hipLaunchKernelGGL(voxel_emit_kernel, dim3((unsigned)((rows + block - 1) / block)), dim3(block), 0, ctx->stream,
+        hipLaunchKernelGGL(voxel_emit_kernel, dim3((unsigned)((in->n + block - 1) / block)), dim3(block), 0, ctx->stream,
                            (const pcr_pt*)in->d, (const unsigned int*)w.perm, (const unsigned int*)w.heads, (const unsigned int*)w.n_groups,
                            (long long)in->n, mode, (unsigned long long)seed, out_pts, out_xyz_dev);
         PCR_HIP(ctx, hipGetLastError());
     }
+    unsigned int ng = 0;
+    PCR_HIP(ctx, hipMemcpyAsync(&ng, w.n_groups, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t rows = mode == 2 ? (int64_t)ng : (ng > 0 ? (int64_t)ng - 1 : 0);
     *n_out = rows;
     voxel_release(ctx, &w);
     return PCR_OK;
