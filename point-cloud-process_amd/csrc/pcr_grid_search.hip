@@ -1,39 +1,33 @@
 // Exact 1-NN search over the multi-level voxel-hash grid (see pcr_grid.hip for the layout).
 //
-// Queries are processed in TILES of 64 consecutive records of the Morton-sorted query cloud
-// (a rigid transform keeps a tile spatially compact, so the cloud is sorted once per pair).
+// Queries are processed in WAVE TILES of 16 consecutive records of the Morton-sorted query cloud (a rigid transform
+// keeps a tile spatially compact, so the cloud is sorted once per pair).
 //
-//   tile    one 256-thread block per tile: bounding box of the tile's cells (+1 ring) at the
-//           finest level whose box has <= 512 cells; every thread looks up cells of the box in
-//           the hash table (2-3 lookups per query instead of 27); the points of the occupied
-//           cells are staged ONCE into LDS with coalesced reads; then every query is compared
-//           with every staged point (LDS broadcast reads, no global traffic, no divergence).
-//           A query is resolved when its bound ball (best distance so far, or the gate) lies
-//           inside the staged box.  Measured alternatives, all exact, all slower on the 120k
-//           KITTI-shaped pair: 8 lanes/query over the 27 cells with lane-owned cells (117 us),
-//           flattened directory (174 us), prune-then-visit (88-180 us) -- dependent
-//           lookup->scan chains and uncoalesced 32-B reads dominate there.
-//   hard    every query the tile stage could not resolve (bound ball sticks out of the staged box,
-//           or the tile's box holds too many points to stage), one wave per query: pruned top-down
-//           descent of the nested cell hierarchy (cells are contiguous runs of the Morton-sorted
-//           target at every level), 64 children box-tested per step.
-// The unresolved queries of a tile are appended to ONE global list with a single atomic per block
-// (a per-query global append saturates at ~88 appends/us on this chip and cost more than the search).
-// Pruning only ever skips a cell whose box distance exceeds a bound that is itself >= the
-// final answer, so every stage returns the exact nearest neighbour (lowest index on ties).
+//   wave tile   one wave per tile, no block-level barrier: box of the cubes its queries claim (cells + 1 ring at first,
+//               bound balls later; inside the ICP loop the previous pass's neighbour bounds every ball at once), directory
+//               through the 2x2x2-block table (one probe per lane), the box's points staged ONCE into the wave's LDS
+//               slice as binary32 coordinates about the box centre, every query compared with every staged point by
+//               packed binary32 math with a rigorous binary64 verification bound; up to three passes.
+//   hard        what a tile cannot prove (ambiguous filter results, balls that need too many cells or points, no
+//               neighbour inside the gate), one wave per query: pruned descent of the nested cell hierarchy (cells are
+//               contiguous runs of the Morton-sorted target at every level), 64 children box-tested per step.
+//   accumulate  gate + Procrustes moments; inside the ICP loop its last block also solves the 3x3 step and tests
+//               convergence, so the host is out of the iteration.
+// Round 1's stage was a 64-query tile per 256-thread block (4 barriers per tile, ~980 staged candidates per query, all
+// resident tiles in lockstep): 40 us for the same pass that takes the wave tiles ~30 us with a third of the hard-stage
+// work; DESIGN.md section 7 keeps its measurements.  Measured alternatives before that, all exact, all slower on the
+// 120k KITTI-shaped pair: 8 lanes/query over the 27 cells (117 us), flattened directory (174 us), prune-then-visit
+// (88-180 us) -- dependent lookup->scan chains and uncoalesced 32-B reads dominate there.
+// The unresolved queries of a tile are appended to one of 32 lists with a single atomic per wave (a per-query global
+// append saturates at ~88 appends/us on this chip and cost more than the search).  Pruning only ever skips a cell whose
+// box distance exceeds a bound that is itself >= the final answer, so every stage returns the exact nearest neighbour
+// (lowest index on ties).
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include "pcr_grid_dev.h"
 #include "pcr_icp_step.h"
 
-constexpr int TQ = 64;                      // queries per tile (= slots per block in the work lists)
-constexpr int T_MAXC = 512;                 // cells in a tile box (1024: more sparse tiles stay at a fine level and leave their queries unresolved; 256 and below: boxes at the coarser level overflow the candidate cap)
-constexpr int T_PMAX = 512;                 // points staged per round
-// Tiles with more candidate points than the cap go per-query to the hard stage.  The cap is chosen per launch: 4 rounds
-// (2048 points) when the grid is a single generation of blocks and a long tile would be the kernel's tail, 16 rounds when
-// there are several generations (a dense 1M-point scan sent 40 % of its queries to the hard stage with the small cap).
-constexpr unsigned int T_PCAP_SMALL = 4 * T_PMAX, T_PCAP_LARGE = 16 * T_PMAX;
 constexpr unsigned int HARD_SCAN_T = 192;   // the hard stage scans cells up to this size, descends into bigger ones
 constexpr int HARD_STACK = 160;
 constexpr long long ID_NONE = 0x7fffffffffffffffll;
@@ -85,379 +79,6 @@ __device__ static inline double sq_pos(double v) {
     return v * v;
 }
 
-// -------------------------------------------------------------------- tile
-struct tile_smem {
-    alignas(16) float px[T_PMAX + 8], py[T_PMAX + 8], pz[T_PMAX + 8];  // staged candidates, binary32 about the tile centre (SoA, padded to 8)
-    unsigned int ppos[T_PMAX];
-    unsigned int c_start[T_MAXC];
-    unsigned int c_off[T_MAXC + 1];  // exclusive prefix of the cell counts
-    float m_m[4][TQ], m_s[4][TQ];  // per wave: smallest and second-smallest filter distance of each query
-    unsigned int m_pos[4][TQ];
-    unsigned int scan_tmp[256];
-    int box_lo[3], dims[3];
-    int level, ncell;
-    unsigned int total;
-};
-
-__global__ void __launch_bounds__(256)
-grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
-                 int gated, int xcd_remap, unsigned int pcap, int maxc, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, work_item* __restrict__ hard_list,
-                 unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg, const pcr_icp_dev_state* __restrict__ st) {
-    __shared__ tile_smem sm;
-    if (st) {  // device-resident ICP loop: this pass applies the increment the previous pass solved; no-op behind a stop
-        if (st->stop) return;
-        x = st->x;
-    }
-    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
-    unsigned long long t_ph[5] = {0, 0, 0, 0, 0};
-#define PH_STAMP(i) do { if (dbg) t_ph[i] = __builtin_amdgcn_s_memtime() - t_start; } while (0)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8), each XCD with its own L2: give every XCD one
-    // contiguous run of tiles (= one compact region of the scan), so that the hash slots and target records a tile needs
-    // are mostly those its neighbours on the same L2 already fetched.  PCR_TILE_XCD=0 restores the plain order.
-    unsigned int tile = blockIdx.x;
-    if (xcd_remap) {
-        const unsigned int per = gridDim.x >> 3, main = per << 3;  // the last gridDim.x % 8 tiles keep their index
-        if (tile < main) tile = (tile & 7u) * per + (tile >> 3);
-    }
-    const long long qi = (long long)tile * TQ + lane;  // every wave holds the same 64 queries
-    const bool qvalid = qi < nq;
-    // ---- load + transform the tile's queries (wave 0 writes back)
-    double ax = 0, ay = 0, az = 0;
-    long long qid = 0;
-    bool clamped = false;
-    int cx = 0, cy = 0, cz = 0;
-    if (qvalid) {
-        pcr_pt p = q[qi];
-        ax = p.x; ay = p.y; az = p.z;
-        qid = p.id;
-        if (has_x) xform_apply(x, p, &ax, &ay, &az);
-        cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
-        cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
-        cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
-    }
-    const bool in_box = qvalid && !clamped;
-    // ---- bounding box of the tile's level-0 cells (wave 0), then the level whose box fits T_MAXC cells
-    if (wave == 0) {
-        int mn[3] = {in_box ? cx : 0x7fffffff, in_box ? cy : 0x7fffffff, in_box ? cz : 0x7fffffff};
-        int mx[3] = {in_box ? cx : -1, in_box ? cy : -1, in_box ? cz : -1};
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                mn[k] = min(mn[k], __shfl_xor(mn[k], off, 64));
-                mx[k] = max(mx[k], __shfl_xor(mx[k], off, 64));
-            }
-        }
-        if (lane == 0) {
-            int level = -1;
-            if (mx[0] >= 0) {
-                for (int l = 0; l < gv.levels; ++l) {
-                    const long long d0 = (mx[0] >> (2 * l)) - (mn[0] >> (2 * l)) + 3, d1 = (mx[1] >> (2 * l)) - (mn[1] >> (2 * l)) + 3,
-                                    d2 = (mx[2] >> (2 * l)) - (mn[2] >> (2 * l)) + 3;
-                    if (d0 * d1 * d2 <= (long long)maxc) {
-                        level = l;
-                        sm.box_lo[0] = (mn[0] >> (2 * l)) - 1; sm.box_lo[1] = (mn[1] >> (2 * l)) - 1; sm.box_lo[2] = (mn[2] >> (2 * l)) - 1;
-                        sm.dims[0] = (int)d0; sm.dims[1] = (int)d1; sm.dims[2] = (int)d2;
-                        sm.ncell = (int)(d0 * d1 * d2);
-                        break;
-                    }
-                }
-            }
-            sm.level = level;
-        }
-    }
-    __syncthreads();
-    // in-place transform of the source (main.py:110): wave 0 stores, and only after the barrier -- every wave of the
-    // block has loaded the untransformed record by now (a store before it raced with the other waves' loads)
-    if (has_x && write_back && wave == 0 && qvalid) {
-        pcr_pt p;
-        p.x = ax; p.y = ay; p.z = az; p.id = qid;
-        q[qi] = p;
-    }
-    PH_STAMP(0);
-    const int level = sm.level;
-    double bd2 = DBL_MAX;
-    long long bid = ID_NONE;
-    unsigned int bpos = POS_NONE;
-    bool staged = false;
-    if (level >= 0) {
-        // ---- cell directory: every thread looks up cells of the box
-        const int ncell = sm.ncell;
-        const int d0 = sm.dims[0], d1 = sm.dims[1], d01 = d0 * d1;
-        const int lim = (int)(PCR_COORD_MAX >> (2 * level));
-        // Directory of the box's cells through the 2x2x2-block table: one 32-byte slot answers 8 cells (their runs are
-        // consecutive in the sorted cloud), so a tile reads ~ncell/5 random lines instead of ncell.  (The gather rounds
-        // of this kernel are bound by the misses a CU can keep in flight, not by bytes or address-coalescer cycles:
-        // four 16-byte loads per lane and one coalesced line per quad took the same 12 us.)
-        {
-            for (int c = tid; c < ncell; c += 256) { sm.c_start[c] = 0; sm.c_off[c] = 0; }
-            const int bx0 = sm.box_lo[0] >> 1, by0 = sm.box_lo[1] >> 1, bz0 = sm.box_lo[2] >> 1;
-            const int nb0 = ((sm.box_lo[0] + d0 - 1) >> 1) - bx0 + 1, nb1 = ((sm.box_lo[1] + d1 - 1) >> 1) - by0 + 1;
-            const int nb2 = ((sm.box_lo[2] + sm.dims[2] - 1) >> 1) - bz0 + 1;
-            const int nb01 = nb0 * nb1, nblk = nb01 * nb2;
-            const float binv0 = 1.0f / (float)nb0, binv01 = 1.0f / (float)nb01;
-            const int blim = lim >> 1;
-            __syncthreads();
-            for (int bq = tid; bq < nblk; bq += 256) {
-                int iz = (int)((float)bq * binv01);
-                iz -= (__mul24(iz, nb01) > bq);  // 24-bit multiplies: full rate (v_mul_lo_u32 is a quarter-rate op)
-                iz += (__mul24(iz + 1, nb01) <= bq);
-                const int rem = bq - __mul24(iz, nb01);
-                int iy = (int)((float)rem * binv0);
-                iy -= (__mul24(iy, nb0) > rem);
-                iy += (__mul24(iy + 1, nb0) <= rem);
-                const int ix = rem - __mul24(iy, nb0);
-                const int BX = bx0 + ix, BY = by0 + iy, BZ = bz0 + iz;
-                if (BX < 0 || BY < 0 || BZ < 0 || BX > blim || BY > blim || BZ > blim) continue;
-                pcr_block_slot e;
-                if (!lookup_block(gv.btable[level], gv.bmask[level], (unsigned int)BX, (unsigned int)BY, (unsigned int)BZ, &e)) continue;
-                unsigned int run = e.start;
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
-                    const int X = 2 * BX + (ch & 1) - sm.box_lo[0], Y = 2 * BY + ((ch >> 1) & 1) - sm.box_lo[1], Z = 2 * BZ + (ch >> 2) - sm.box_lo[2];
-                    unsigned int cs = run, cn = e.cnt[ch];
-                    if (e.flags) {  // a child too large for 16 bits: ask the cell table
-                        unsigned int s2 = 0, e2 = 0;
-                        lookup_cell(gv.table[level], gv.mask[level], (unsigned int)(2 * BX + (ch & 1)), (unsigned int)(2 * BY + ((ch >> 1) & 1)),
-                                    (unsigned int)(2 * BZ + (ch >> 2)), &s2, &e2);
-                        cs = s2; cn = e2 - s2;
-                    }
-                    run += cn;
-                    if (X >= 0 && Y >= 0 && Z >= 0 && X < d0 && Y < d1 && Z < sm.dims[2]) {
-                        const int c = X + __mul24(Y, d0) + __mul24(Z, d01);
-                        sm.c_start[c] = cs;
-                        sm.c_off[c] = cn;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        PH_STAMP(1);
-        // block exclusive scan of the cell counts held in c_off: thread t owns cells 4t .. 4t+3
-        {
-            unsigned int cnt4[4];
-            unsigned int mine = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = tid * 4 + u;
-                cnt4[u] = c < ncell ? sm.c_off[c] : 0u;
-                mine += cnt4[u];
-            }
-            unsigned int inc = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned int o = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += o;
-            }
-            if (lane == 63) sm.scan_tmp[wave] = inc;
-            __syncthreads();
-            unsigned int base = 0, run = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const unsigned int t = sm.scan_tmp[w];
-                if (w < wave) base += t;
-                run += t;
-            }
-            unsigned int pre = base + inc - mine;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = tid * 4 + u;
-                if (c < ncell) sm.c_off[c] = pre;
-                pre += cnt4[u];
-            }
-            if (tid == 0) { sm.c_off[ncell] = run; sm.total = run; }
-            __syncthreads();
-        }
-        PH_STAMP(2);
-        const unsigned int total = sm.total;
-        // Filter + verify.  The 64 x P comparisons run in binary32 on coordinates taken about the tile
-        // centre (packed v_pk_* math, 2 candidates per instruction), tracking per query the smallest and the
-        // second-smallest filter distance.  With e = bound on the coordinate error, the exact nearest
-        // neighbour X and the filter's winner Y satisfy d~(X)^2 <= U(d~(Y)^2); so when the second-smallest
-        // filter distance exceeds U the winner IS the exact nearest neighbour (its distance is then
-        // recomputed in binary64, direct form).  Otherwise the query is ambiguous (near-tie or duplicate
-        // targets) and goes to the exact hard stage.
-        float fm = INFINITY, fs = INFINITY;  // smallest / second smallest group minimum of the filter distances
-        float s_in = INFINITY;               // runner-up inside the winner's own group
-        if (total <= pcap) {
-            staged = true;
-            const double cellL = gv.cell0 * (double)(1ll << (2 * level));
-            const int blL = (int)(PCR_COORD_BIAS >> (2 * level));
-            const double ox = gv.lo[0] + ((double)(sm.box_lo[0] - blL) + 0.5 * sm.dims[0]) * cellL;
-            const double oy = gv.lo[1] + ((double)(sm.box_lo[1] - blL) + 0.5 * sm.dims[1]) * cellL;
-            const double oz = gv.lo[2] + ((double)(sm.box_lo[2] - blL) + 0.5 * sm.dims[2]) * cellL;
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            const float qxf = (float)(ax - ox), qyf = (float)(ay - oy), qzf = (float)(az - oz);
-            const f2 qx2 = {qxf, qxf}, qy2 = {qyf, qyf}, qz2 = {qzf, qzf};
-            // ---- rounds: stage up to T_PMAX points into LDS, compare every query with every staged point
-            for (unsigned int base = 0; base < total; base += T_PMAX) {
-                const unsigned int wend = min(total, base + T_PMAX);
-                const unsigned int cnt = wend - base;
-                // staging: thread t copies staged points t, t+256, ...; the owning cell is found by binary
-                // search in the prefix array, so all global reads of a round are independent
-                for (unsigned int f = base + tid; f < wend; f += 256) {
-                    int lo = 0, hi = ncell - 1;
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (sm.c_off[mid] <= f) lo = mid;
-                        else hi = mid - 1;
-                    }
-                    const unsigned int j = sm.c_start[lo] + (f - sm.c_off[lo]);
-                    const pcr_pt b = gv.pts[j];
-                    const unsigned int k = f - base;
-                    sm.px[k] = (float)(b.x - ox); sm.py[k] = (float)(b.y - oy); sm.pz[k] = (float)(b.z - oz);
-                    sm.ppos[k] = j;
-                }
-                PH_STAMP(3);
-                if (tid < 8) { sm.px[cnt + tid] = 1e30f; sm.py[cnt + tid] = 0.0f; sm.pz[cnt + tid] = 0.0f; }  // padding of the last group of 8
-                __syncthreads();
-                // evaluation: wave w takes groups of 8 staged points; lane = query.  Per group: 12 packed ops for the 8
-                // distances, 4 v_min3/v_min for the group minimum, then ONE tracker update (smallest / second-smallest
-                // group minimum, and which group) -- 4 VALU ops per candidate instead of 7 with a per-candidate tracker.
-                // The winner's position inside its group and the group's own runner-up are recovered after the round.
-                int rk = -1;
-                for (unsigned int k0 = wave * 8; k0 < cnt; k0 += 32) {
-                    f2 d[4];
-                    typedef float f4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {  // 16-byte LDS reads: 4 candidates per ds_read_b128
-                        const unsigned int k = k0 + 4 * u;
-                        const f4 bx4 = *reinterpret_cast<const f4*>(&sm.px[k]);
-                        const f4 by4 = *reinterpret_cast<const f4*>(&sm.py[k]);
-                        const f4 bz4 = *reinterpret_cast<const f4*>(&sm.pz[k]);
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const f2 bx = h ? f2{bx4.z, bx4.w} : f2{bx4.x, bx4.y};
-                            const f2 by = h ? f2{by4.z, by4.w} : f2{by4.x, by4.y};
-                            const f2 bz = h ? f2{bz4.z, bz4.w} : f2{bz4.x, bz4.y};
-                            const f2 dx = qx2 - bx, dy = qy2 - by, dz = qz2 - bz;
-                            f2 t = dx * dx;
-                            t = __builtin_elementwise_fma(dy, dy, t);
-                            d[2 * u + h] = __builtin_elementwise_fma(dz, dz, t);
-                        }
-                    }
-                    float m8 = fmin3(d[0].x, d[0].y, d[1].x);
-                    m8 = fmin3(m8, d[1].y, d[2].x);
-                    m8 = fmin3(m8, d[2].y, d[3].x);
-                    m8 = fmin3(m8, d[3].y, d[3].y);
-                    const bool lt = m8 < fm;
-                    fs = __builtin_amdgcn_fmed3f(m8, fm, fs);           // second smallest of {fm <= fs, m8}
-                    fm = __builtin_amdgcn_fmed3f(m8, fm, -INFINITY);     // min(m8, fm)
-                    rk = lt ? (int)k0 : rk;
-                }
-                if (rk >= 0) {
-                    // this round produced the wave's current winner: locate it in its group; the group's runner-up joins
-                    // the second-smallest test (every other group is covered by fs)
-                    float best = INFINITY, second = INFINITY;
-                    int bi = rk;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float ddx = qxf - sm.px[rk + j], ddy = qyf - sm.py[rk + j], ddz = qzf - sm.pz[rk + j];
-                        const float dj = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx));
-                        if (dj < best) { second = best; best = dj; bi = rk + j; }
-                        else if (dj < second) second = dj;
-                    }
-                    bpos = sm.ppos[bi];
-                    s_in = second;
-                }
-                __syncthreads();
-            }
-        }
-        sm.m_m[wave][lane] = fm;
-        sm.m_s[wave][lane] = fminf(fs, s_in);
-    } else {
-        sm.m_m[wave][lane] = INFINITY;
-        sm.m_s[wave][lane] = INFINITY;
-    }
-    PH_STAMP(4);
-    // ---- merge the four waves' results per query, then verify in binary64
-    sm.m_pos[wave][lane] = bpos;
-    __syncthreads();
-    unsigned int n_unres = 0;
-    if (wave == 0) {
-        bool unres = false;
-        if (qvalid) {
-            float M = sm.m_m[0][lane], S = sm.m_s[0][lane];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float mw = sm.m_m[w][lane], sw = sm.m_s[w][lane];
-                S = fminf(fmaxf(M, mw), fminf(S, sw));
-                if (mw < M) { M = mw; bpos = sm.m_pos[w][lane]; }
-            }
-            bool ambiguous = false;
-            if (staged && bpos != POS_NONE) {
-                // coordinate error of the filter: |local coordinate| <= R, binary32 conversion + subtraction
-                const double cellL = gv.cell0 * (double)(1ll << (2 * level));
-                const double R = 0.5 * cellL * (double)max(sm.dims[0], max(sm.dims[1], sm.dims[2]));
-                const double e = 8.0 * 5.9604644775390625e-08 * R;
-                const double dhi = sqrt((double)M * (1.0 + 1e-6)) + e;
-                const double U = (dhi + e) * (dhi + e) * (1.0 + 1e-6);
-                ambiguous = (double)S <= U;
-                if (res_d2) {
-                    const pcr_pt b = gv.pts[bpos];
-                    bd2 = dist2(ax, ay, az, b);  // exact, direct form (the nn1 API reports it)
-                    bid = b.id;
-                } else {
-                    // ICP pass: the epilogue recomputes the exact distance from the matched record anyway, so the
-                    // dependent 32-byte read is skipped here; U bounds the winner's true squared distance from above,
-                    // which is all the in-box test and the hard stage's first bound need
-                    bd2 = U;
-                }
-            }
-            if (clamped || !staged) {
-                unres = true;  // nothing usable is known about this query yet
-                bd2 = DBL_MAX;
-                bpos = POS_NONE;
-            } else {
-                // distance from the query to the boundary of the staged box
-                const double cell = gv.cell0 * (double)(1ll << (2 * level));
-                const int bl = (int)(PCR_COORD_BIAS >> (2 * level));
-                double db = DBL_MAX;
-                const double a[3] = {ax, ay, az};
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double blo = gv.lo[k] + (double)(sm.box_lo[k] - bl) * cell;
-                    const double bhi = gv.lo[k] + (double)(sm.box_lo[k] + sm.dims[k] - bl) * cell;
-                    db = fmin(db, fmin(a[k] - blo, bhi - a[k]));
-                }
-                db = fmax(db - cell * 1e-9, 0.0);
-                const double bound2 = gated ? fmin(bd2, max_d2) : bd2;
-                if (bound2 <= db * db && !ambiguous) {  // the bound ball lies inside the staged box: exact
-                    res_pos[qi] = bpos;
-                    if (res_d2) res_d2[qi] = bd2;
-                } else {
-                    unres = true;
-                }
-            }
-        }
-        // one append per block: reserve a run of the global hard list for this tile's unresolved queries
-        const unsigned long long m = __ballot(unres);
-        n_unres = __popcll(m);
-        if (m) {
-            unsigned int base = 0;
-            const unsigned int hl = tile % H_NLIST;
-            if (lane == 0) base = hl * hard_list_cap(nq) + atomicAdd(hard_count + H_CSTRIDE * hl, n_unres);
-            base = __shfl(base, 0, 64);
-            if (unres) {
-                work_item it;
-                it.ax = ax; it.ay = ay; it.az = az;
-                it.best_d2 = bd2;
-                it.best_pos = bpos;
-                it.qi = (unsigned int)qi;
-                hard_list[base + __popcll(m & ((1ull << lane) - 1ull))] = it;
-            }
-        }
-    }
-    if (dbg && tid == 0) {
-        dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - t_start;
-        for (int i = 0; i < 5; ++i) dbg[(1 << 16) + blockIdx.x * 8 + i] = t_ph[i];
-        dbg[blockIdx.x * 4 + 1] = (level >= 0) ? sm.total : 0xffffffffu;
-        dbg[blockIdx.x * 4 + 2] = ((unsigned long long)(level + 1) << 32) | (unsigned)sm.ncell;
-        dbg[blockIdx.x * 4 + 3] = n_unres;
-    }
-}
-
 // --------------------------------------------------------------- wave tile
 // Second-generation tile stage: ONE WAVE = one tile of 16 consecutive queries, no block-level barrier anywhere.
 // Why: with 64-query tiles every query was compared with the union of 64 neighbourhoods (~980 staged points per
@@ -474,10 +95,13 @@ grid_tile_kernel(pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, pcr_xfo
 //   that was actually staged and the filter's second-best exceeds U.  What is still open after the last pass
 //   (ambiguous filter results, boxes with too many points, clamped coordinates) goes to the hard stage.
 #ifndef PCR_WT_Q
-#define PCR_WT_Q 16
+#define PCR_WT_Q 32
 #endif
 constexpr int WT_Q = PCR_WT_Q;      // queries per wave tile (16 or 32)
-constexpr int WT_MAXC = 128;        // cells in a wave-tile box
+#ifndef PCR_WT_MAXC
+#define PCR_WT_MAXC 384
+#endif
+constexpr int WT_MAXC = PCR_WT_MAXC;        // cells in a wave-tile box (a 7 x 7 x 7 box = 64 two-cell blocks fits: the gate ball of a sparse-region query at 0.8 m cells)
 constexpr int WT_PR = 192;          // points staged per round (3 chunks of 64, loaded back to back)
 constexpr int WT_PASSES = 3;
 constexpr int WT_ROUNDS_SMALL = 4, WT_ROUNDS_LARGE = 12;
@@ -522,6 +146,23 @@ __device__ static inline unsigned int wave_incl_scan_max(unsigned int v) {
     v = max(v, dpp_u32<0x143, 0xc>(0u, v));
     return v;
 }
+// binary64 wave total in lane 63 (inclusive-scan pattern; lanes without a source add +0.0)
+template <int CTRL, int ROW_MASK>
+__device__ static inline double dpp_add_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ static inline double wave_total_f64(double v) {
+    v = dpp_add_f64<0x111, 0xf>(v);
+    v = dpp_add_f64<0x112, 0xf>(v);
+    v = dpp_add_f64<0x114, 0xf>(v);
+    v = dpp_add_f64<0x118, 0xf>(v);
+    v = dpp_add_f64<0x142, 0xa>(v);
+    v = dpp_add_f64<0x143, 0xc>(v);
+    return v;
+}
+
 // all-reduce inside every row of 16 lanes (= the 16 queries of a candidate slice): quad swaps, half mirror, mirror
 __device__ static inline int row16_min(int v) {
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
@@ -552,11 +193,14 @@ __device__ static inline const T* as_global(const T* p) {
     return (const T*)(const __attribute__((address_space(1))) T*)p;
 }
 
-__global__ void __launch_bounds__(256)
+#ifndef PCR_WT_WAVES
+#define PCR_WT_WAVES 4   // keep the register allocator at <= 128 VGPRs: it drifts to 130-145 (3 waves per SIMD) on small edits
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
 grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
                   int gated, int xcd_remap, unsigned int pcap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2,
                   work_item* __restrict__ hard_list, unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg,
-                  const pcr_icp_dev_state* __restrict__ st, int use_prev) {
+                  const pcr_icp_dev_state* __restrict__ st, const wt_xyz* __restrict__ prev_xyz) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ wtile_lds s_lds[4];
@@ -567,8 +211,15 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
     const pcr_grid_view& gv = *gvp;  // uniform address: fields arrive by scalar loads when they are needed
     const pcr_pt* __restrict__ g_pts = as_global(gv.pts);
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#ifdef PCR_WT_DIAG   // phase stamps + "why still open" counters for scripts/wt_stamps.py: a diagnostic build only (they cost registers)
     unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = t_start;
 #define WT_STAMP(i) do { if (dbg) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_ph[i] += t_now - t_last; t_last = t_now; } } while (0)
+#define WT_WHY(v) do { why = (v); } while (0)
+    int why = 0;   // why the query was still open after its last pass (1 level, 2 too many points, 3 ambiguous, 4 ball out of the box)
+#else
+#define WT_STAMP(i) do {} while (0)
+#define WT_WHY(v) do {} while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     wtile_lds* L = &s_lds[wave];
     unsigned int blk = blockIdx.x;
@@ -604,13 +255,15 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
     const float gate2 = gated ? (float)max_d2 * (1.0f + 1e-6f) : INFINITY;   // rounded up: only ever used as an outer bound
     float bound2 = gate2;                       // squared radius that provably holds the nearest neighbour (or the gate)
     unsigned int cand_pos = POS_NONE;
-    if (use_prev && qvalid && !clamped) {
+    if (prev_xyz && qvalid && !clamped) {
         // ICP iterations after the first: res_pos still holds every query's neighbour of the PREVIOUS pass (the target
-        // never changes).  Its exact distance from the query's new position bounds the search ball at once, so the
-        // first box is the bounding box of tight balls instead of cells + 1 ring, and one pass proves almost every query.
+        // never changes) and prev_xyz its coordinates (the accumulate kernel, which gathers the record anyway, leaves them
+        // there: no dependent gather here).  The exact distance from the query's new position to that point bounds the
+        // search ball at once, so the first box is the bounding box of tight balls instead of cells + 1 ring, and one
+        // pass proves almost every query.
         const unsigned int pp = res_pos[qi];
         if (pp != POS_NONE) {
-            const wt_xyz b = *reinterpret_cast<const wt_xyz*>(&g_pts[pp]);
+            const wt_xyz b = prev_xyz[qi];
             const double dx = ax - b.x, dy = ay - b.y, dz = az - b.z;
             const float up = (float)((dx * dx + dy * dy) + dz * dz) * (1.0f + 2e-7f) + 1e-37f;   // rounded up
             if (up < bound2) { bound2 = up; cand_pos = pp; }
@@ -661,7 +314,7 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
             break;
         }
         level = __builtin_amdgcn_readfirstlane(level);
-        if (level < 0) break;
+        if (level < 0) { if (part) WT_WHY(1); break; }
         blo0 = __builtin_amdgcn_readfirstlane(blo0); blo1 = __builtin_amdgcn_readfirstlane(blo1); blo2 = __builtin_amdgcn_readfirstlane(blo2);
         d0 = __builtin_amdgcn_readfirstlane(d0); d1 = __builtin_amdgcn_readfirstlane(d1); d2 = __builtin_amdgcn_readfirstlane(d2);
         ++dbg_passes;
@@ -716,22 +369,19 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
         }
         wave_sync();
         WT_STAMP(2);
-        // ---- exclusive prefix of the cell counts in slot order (<= WT_MAXC = 2 x 64 cells)
+        // ---- exclusive prefix of the cell counts in slot order (chunks of 64 cells, running total carried along)
         unsigned int total = 0;
-        {
-            unsigned int t0 = 0, t1 = 0;
-            const unsigned int c0 = (unsigned int)lane < ncell ? L->c_off[lane] : 0u;
-            const unsigned int c1 = (unsigned int)(lane + 64) < ncell ? L->c_off[lane + 64] : 0u;
-            const unsigned int p0 = wave_excl_scan_u32(c0, lane, &t0);
-            unsigned int p1 = 0;
-            if (ncell > 64) p1 = wave_excl_scan_u32(c1, lane, &t1);
-            if ((unsigned int)lane < ncell) L->c_off[lane] = p0;
-            if ((unsigned int)(lane + 64) < ncell) L->c_off[lane + 64] = t0 + p1;
-            total = t0 + t1;
+        for (unsigned int c0 = 0; c0 < ncell; c0 += 64) {
+            const unsigned int c = c0 + lane;
+            const unsigned int cn = c < ncell ? L->c_off[c] : 0u;
+            unsigned int t = 0;
+            const unsigned int pre = wave_excl_scan_u32(cn, lane, &t);
+            if (c < ncell) L->c_off[c] = total + pre;
+            total += t;
         }
         wave_sync();
         WT_STAMP(3);
-        if (total > pcap) continue;   // too many points to stage around this tile: a later pass has tighter balls, or the hard stage takes over
+        if (total > pcap) { if (part) WT_WHY(2); continue; }   // too many points to stage around this tile: a later pass has tighter balls, or the hard stage takes over
         if (dbg) dbg_pairs += (unsigned long long)total * (unsigned long long)__popcll(__ballot(part && lane < WT_Q));
         const float cellLf = (float)gv.cell0 * (float)(1 << (2 * level));
         const double cellL = gv.cell0 * (double)(1ll << (2 * level));
@@ -876,9 +526,12 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
                     }
                     res_pos[qi] = bpos;
                 }
-            } else if (bpos != POS_NONE && U < bound2) {
-                bound2 = U;           // a real candidate: the next pass (or the hard stage) searches inside its ball
-                cand_pos = bpos;
+            } else {
+                WT_WHY(ambiguous ? 3 : 4);
+                if (bpos != POS_NONE && U < bound2) {
+                    bound2 = U;       // a real candidate: the next pass (or the hard stage) searches inside its ball
+                    cand_pos = bpos;
+                }
             }
         }
     }
@@ -901,14 +554,25 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
             hard_list[base + __popcll(m & ((1ull << lane) - 1ull))] = it;
         }
     }
+#ifdef PCR_WT_DIAG
+    unsigned int dbg_why[5] = {0, 0, 0, 0, 0};
+    if (dbg)
+        for (int r = 0; r < 5; ++r) dbg_why[r] = (unsigned int)__popcll(__ballot(unres && (clamped ? 0 : why) == r));
+#endif
     if (dbg && lane == 0) {
         atomicAdd(&dbg[blockIdx.x * 4 + 1], dbg_pairs);
         atomicAdd(&dbg[blockIdx.x * 4 + 2], (unsigned long long)dbg_passes);
         atomicAdd(&dbg[blockIdx.x * 4 + 3], (unsigned long long)__popcll(m));
+#ifdef PCR_WT_DIAG
+        for (int r = 0; r < 5; ++r)
+            if (dbg_why[r]) atomicAdd(&dbg[(1 << 15) + r], (unsigned long long)dbg_why[r]);
+#endif
         atomicMax(&dbg[blockIdx.x * 4 + 0], __builtin_amdgcn_s_memtime() - t_start);
+#ifdef PCR_WT_DIAG
         WT_STAMP(7);
         if (wave == 0)
             for (int i = 0; i < 8; ++i) dbg[(1 << 16) + blockIdx.x * 8 + i] = t_ph[i];
+#endif
     }
 }
 
@@ -1207,7 +871,7 @@ __global__ void __launch_bounds__(256)
 grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long nq, pcr_xform x, int apply_x,
                        const unsigned int* __restrict__ res_pos, double max_d2, int gated, double* __restrict__ partials,
                        unsigned int* __restrict__ ticket, double* __restrict__ out, unsigned int* __restrict__ hard_count,
-                       pcr_icp_dev_state* __restrict__ st, pcr_icp_loop_args la) {
+                       pcr_icp_dev_state* __restrict__ st, pcr_icp_loop_args la, wt_xyz* __restrict__ prev_xyz) {
     __shared__ double s_part[4][PCR_NMOM];
     if (st && st->stop) return;
     double m[PCR_NMOM];
@@ -1232,6 +896,11 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (pos[u] != POS_NONE) b[u] = gv.pts[pos[u]];
+        if (prev_xyz) {  // seed of the next pass's wave tiles (coalesced 24-byte stores, off every critical path)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pos[u] != POS_NONE) prev_xyz[q0 + u * stride] = wt_xyz{b[u].x, b[u].y, b[u].z};
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (pos[u] == POS_NONE) continue;
@@ -1252,15 +921,12 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
             m[18] += d2;
         }
     }
+    // wave totals on the DPP network (fixed order, total in lane 63): a __shfl_xor butterfly is 6 dependent ds_bpermute round
+    // trips per moment -- 114 of them were most of this kernel's wave lifetime
 #pragma unroll
-    for (int k = 0; k < PCR_NMOM - 1; ++k) {
-        double v = m[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        m[k] = v;
-    }
+    for (int k = 0; k < PCR_NMOM - 1; ++k) m[k] = wave_total_f64(m[k]);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
+    if (lane == 63) {
 #pragma unroll
         for (int k = 0; k < PCR_NMOM; ++k) s_part[wave][k] = m[k];
     }
@@ -1330,6 +996,7 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
 struct grid_scratch {
     unsigned int* res_pos = nullptr;
     double* res_d2 = nullptr;
+    void* prev_xyz = nullptr;         // [nq] x 24 B: coordinates of every query's neighbour of the last ICP pass (device loop only)
     work_item* hard_list = nullptr;   // [nq] worst case
     unsigned int* hard_count = nullptr;
     int64_t nq = 0;
@@ -1358,34 +1025,27 @@ static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
     if (sc->res_pos) pcr_dev_free(ctx, sc->res_pos, sizeof(unsigned int) * sc->nq);
     if (sc->res_d2) pcr_dev_free(ctx, sc->res_d2, sizeof(double) * sc->nq);
     if (sc->hard_list) pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(sc->nq));
-    sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr;
+    if (sc->prev_xyz) pcr_dev_free(ctx, sc->prev_xyz, 24 * (size_t)sc->nq);
+    sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr; sc->prev_xyz = nullptr;
 }
 
 // Enqueues the search stages on `stream` over the `nq` records at `q` (a whole Morton-sorted cloud or a run of it);
 // leaves res_pos (and res_d2 when the scratch has it) on the device.  `st` != null: device-resident ICP loop.
 static int grid_search_enqueue(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, hipStream_t stream, const pcr_xform* x, int write_back,
                                double max_d2, bool gated, bool mark, grid_scratch* sc, const pcr_icp_dev_state* st, bool use_prev = false) {
-    const int nblocks = (int)((nq + TQ - 1) / TQ);
+    const int nblocks = (int)((nq + 63) / 64);
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
     if (mark) pcr_prof_mark(ctx, 0);
     static const int xcd_remap = getenv("PCR_TILE_XCD") ? atoi(getenv("PCR_TILE_XCD")) : 1;
-    static const int maxc_env = getenv("PCR_TILE_MAXC") ? atoi(getenv("PCR_TILE_MAXC")) : 0;
-    const int maxc = maxc_env > 0 && maxc_env <= T_MAXC ? maxc_env : T_MAXC;
-    static const int pcap_env = getenv("PCR_TILE_PCAP") ? atoi(getenv("PCR_TILE_PCAP")) : 0;
-    const unsigned int pcap = pcap_env > 0 ? (unsigned int)pcap_env : (nblocks > 8 * ctx->cu_count ? T_PCAP_LARGE : T_PCAP_SMALL);
-    static const int old_tile = getenv("PCR_TILE_OLD") ? atoi(getenv("PCR_TILE_OLD")) : 0;
-    if (old_tile) {
-        hipLaunchKernelGGL(grid_tile_kernel, dim3(nblocks), dim3(256), 0, stream, idx->view, q, (long long)nq, x ? *x : xi, (x || st) ? 1 : 0,
-                           write_back, max_d2, gated ? 1 : 0, xcd_remap, pcap, maxc, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug, st);
-    } else {
+    {
         static const int wt_rounds_env = getenv("PCR_WT_ROUNDS") ? atoi(getenv("PCR_WT_ROUNDS")) : 0;
         const unsigned int wpcap = (unsigned int)WT_PR * (wt_rounds_env > 0 ? wt_rounds_env : (nblocks > 8 * ctx->cu_count ? WT_ROUNDS_LARGE : WT_ROUNDS_SMALL));
         if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)nblocks), stream);
         const int wblocks = (int)((nq + 4 * WT_Q - 1) / (4 * WT_Q));
         hipLaunchKernelGGL(grid_wtile_kernel, dim3(wblocks), dim3(256), 0, stream, (const pcr_grid_view*)idx->d_view, q, (long long)nq, x ? *x : xi, (x || st) ? 1 : 0,
                            write_back, max_d2, gated ? 1 : 0, xcd_remap, wpcap, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug, st,
-                           use_prev ? 1 : 0);
+                           (const wt_xyz*)(use_prev ? sc->prev_xyz : nullptr));
     }
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
@@ -1454,7 +1114,7 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         pcr_prof_mark(ctx, 2);
         hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, *x,
                            write_back ? 0 : 1, (const unsigned int*)sc.res_pos, max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
-                           d_moments, sc.hard_count, (pcr_icp_dev_state*)nullptr, pcr_icp_loop_args{});
+                           d_moments, sc.hard_count, (pcr_icp_dev_state*)nullptr, pcr_icp_loop_args{}, (wt_xyz*)nullptr);
         pcr_prof_mark(ctx, 3);
         pcr_prof_mark(ctx, 4);
         PCR_HIP(ctx, hipGetLastError());
@@ -1482,7 +1142,7 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, st, idx->view, (const pcr_pt*)(qc->d + q0), (long long)(q1 - q0), *x,
                            write_back ? 0 : 1, (const unsigned int*)sc[l].res_pos, max_d2, gated ? 1 : 0,
                            ctx->h_slabs + (size_t)PCR_NMOM * PCR_SLABS_PER_LANE * l, (unsigned int*)nullptr, (double*)nullptr, sc[l].hard_count,
-                           (pcr_icp_dev_state*)nullptr, pcr_icp_loop_args{});
+                           (pcr_icp_dev_state*)nullptr, pcr_icp_loop_args{}, (wt_xyz*)nullptr);
     }
     hipError_t e = hipGetLastError();
     for (int l = 0; l < used; ++l) {
@@ -1526,6 +1186,10 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     const int64_t nq = qc->n;
     grid_scratch sc;
     if ((rc = grid_scratch_alloc(ctx, nq, false, ctx->d_counters + PCR_HARD_COUNTERS, &sc))) return rc;
+    if ((rc = pcr_dev_alloc(ctx, 24 * (size_t)nq, &sc.prev_xyz))) {
+        grid_scratch_free(ctx, &sc);
+        return rc;
+    }
     int grid = (int)((nq + 1023) / 1024);  // four queries per thread
     if (grid > ctx->cu_count) grid = ctx->cu_count;
     pcr_icp_dev_state* d_st = nullptr;
@@ -1569,7 +1233,7 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             // after the write-back of the tile kernel the cloud already holds the transformed points
             hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, xi,
                                0, (const unsigned int*)sc.res_pos, params->max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
-                               (double*)nullptr, sc.hard_count, d_st, la);
+                               (double*)nullptr, sc.hard_count, d_st, la, (wt_xyz*)sc.prev_xyz);
             pcr_prof_mark(ctx, 3);
             pcr_prof_mark(ctx, 4);
             pcr_prof_finish(ctx);   // per-kernel HIP events (profiling only: one event sync per pass)

@@ -87,11 +87,6 @@ class KDTreeFlann:
         k = min(k, int(max_nn))
         return [k, idx[:k], d2[:k]]
 
-    def search_radius_vector_3d(self, query, radius):
-        q = np.asarray(query, dtype=np.float64).reshape(1, 3)
-        off, idx, dist = self.index.radius(q, float(radius))
-        return [int(off[1]), idx.tolist(), (dist ** 2).tolist()]
-
 
 def _as_index(tgt):
     if isinstance(tgt, TargetIndex):

@@ -19,6 +19,7 @@ ph = buf[(1 << 16):].reshape(nb, 8).astype(np.float64)
 print("cell", index.cell, "blocks", nb)
 print("block cycles pct 50/90/99/max", np.percentile(b[:, 0], [50, 90, 99, 100]), "sum", b[:, 0].sum())
 print("pairs/block pct 50/90/99/max", np.percentile(b[:, 1], [50, 90, 99, 100]), "total", b[:, 1].sum(), "per query", b[:, 1].sum() / NPTS)
+print("open after the last pass by reason [clamped/none, level, too many points, ambiguous, ball out of box]:", buf[(1 << 15):(1 << 15) + 5])
 print("unresolved total", b[:, 3].sum(), "max/block", b[:, 3].max())
 print("pass stats (slot 2):", np.percentile(b[:, 2], [50, 90, 99, 100]))
 names = ["load+xform", "cube+level", "directory", "prefix", "staging", "filter", "merge+verify", "append"]
