@@ -294,9 +294,15 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             int lo_k = row16_min(mn[k]), hi_k = row16_max(mx[k]);   // every row of 16 lanes
-            if (WT_Q == 32) {   // queries 16..31 sit in row 1
+            if (WT_Q >= 32) {   // queries 16..31 sit in row 1 (and 32..63 in rows 2, 3)
                 lo_k = min(__builtin_amdgcn_readlane(lo_k, 0), __builtin_amdgcn_readlane(lo_k, 16));
                 hi_k = max(__builtin_amdgcn_readlane(hi_k, 0), __builtin_amdgcn_readlane(hi_k, 16));
+            }
+            if (WT_Q == 64) {
+                const int lo2 = min(__builtin_amdgcn_readlane(row16_min(mn[k]), 32), __builtin_amdgcn_readlane(row16_min(mn[k]), 48));
+                const int hi2 = max(__builtin_amdgcn_readlane(row16_max(mx[k]), 32), __builtin_amdgcn_readlane(row16_max(mx[k]), 48));
+                lo_k = min(lo_k, lo2);
+                hi_k = max(hi_k, hi2);
             }
             mn[k] = __builtin_amdgcn_readfirstlane(lo_k);
             mx[k] = __builtin_amdgcn_readfirstlane(hi_k);
