@@ -12,7 +12,7 @@
 // EXACTNESS.  The sweep is only a filter; what it returns is proven, not assumed:
 //   * |v - (d^2 + bias)| <= E_q := 2^-48 (|a'_q| + Rt)^2   (Rt = half diagonal of the target box): at most 22
 //     roundings of quantities bounded by (|a'| + |b'|)^2; bias = 2^-38 Rt^2 keeps v > 0.
-//   * tiles are folded in GROUPS of 4; a group's minimum carries the group index in its low 16 mantissa bits
+//   * tiles are folded in GROUPS of BR_GRP = 8; a group's minimum carries the group index in its low 16 mantissa bits
 //     (|packed - v| < 2^-36 v, relative to d^2 + bias now, not to |a'|^2), and per (query, row group) the
 //     smallest AND the second-smallest packed group minimum are kept.
 //   * every row of the winning group is re-evaluated in the direct form (dx*dx+dy*dy)+dz*dz, so the reported
@@ -35,8 +35,13 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int BR_NT = 4;          // query tiles (of 16) per wave -> 64 queries per wave
 constexpr int BR_WAVES = 4;       // waves per block
 constexpr int BR_QPB = BR_NT * 16 * BR_WAVES;  // queries per block = 256
-constexpr int BR_PAD = 8;         // never-winning padding tiles behind the last real one (unconditional prefetch)
-constexpr int BR_PF = 4;          // tiles per prefetch group = tiles per argmin group
+#ifndef PCR_BR_GRP
+#define PCR_BR_GRP 8
+#endif
+constexpr int BR_PF = 4;          // tiles per prefetch block
+constexpr int BR_GRP = PCR_BR_GRP;  // tiles per argmin group (multiple of BR_PF): one tracker update per group
+constexpr int BR_PAD = BR_GRP + BR_PF;  // never-winning padding tiles behind the last real one (unconditional prefetch)
+static_assert(BR_GRP % BR_PF == 0, "argmin group = whole prefetch blocks");
 constexpr double BR_BIAS_REL = 3.6379788070917130e-12;   // 2^-38 (x Rt^2)
 constexpr double BR_ERR_REL = 3.5527136788005009e-15;    // 2^-48 (x (|a'| + Rt)^2)
 constexpr double BR_TRUNC_REL = 5.8207660913467407e-11;  // 2^-34
@@ -143,7 +148,7 @@ brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tg
         // work, less than an L2 round trip).  (2) The 4 MFMAs of tile t are issued BEFORE the min epilogue of tile
         // t-1, so the VALU work runs in the shadow of the matrix pipe.  The epilogue uses plain v_min_f64 (fmin()
         // would add two canonicalising v_max_f64 per call).  Because of the one-tile lag, argmin group G of a split
-        // covers tiles t0 + 4G - 1 .. t0 + 4G + 2 (clipped at t0); the last tile forms a group of its own.
+        // covers tiles t0 + BR_GRP*G - 1 .. t0 + BR_GRP*G + BR_GRP - 2 (clipped at t0); the last tile forms a group of its own.
         // mfma_a is padded with BR_PAD never-winning tiles, so every load below is unconditional: the compiler can
         // then wait with a counted vmcnt(BR_PF) for the tile it needs instead of draining the prefetch.
         double a_cur[BR_PF], a_nxt[BR_PF];
@@ -157,24 +162,30 @@ brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tg
             cq[tt] = v4f64{qn[tt], qn[tt], qn[tt], qn[tt]};
         }
         unsigned int grp = 0;
-        for (long long tb = t0; tb < t1; tb += BR_PF, ++grp) {
-#pragma unroll
-            for (int i = 0; i < BR_PF; ++i) a_nxt[i] = mfma_a[(tb + BR_PF + i) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch up here: hipcc otherwise sinks it next to its first use
+        for (long long tg = t0; tg < t1; tg += BR_GRP, ++grp) {
             double gm[BR_NT];
 #pragma unroll
-            for (int i = 0; i < BR_PF; ++i) {
-                // tiles past t1 inside the last group belong to the next split or are padding: harmless to look at
-                v4f64 cur[BR_NT];
+            for (int h = 0; h < BR_GRP / BR_PF; ++h) {
+                const long long tb = tg + h * BR_PF;
 #pragma unroll
-                for (int tt = 0; tt < BR_NT; ++tt) cur[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[i], bq[tt], cq[tt], 0, 0, 0);
+                for (int i = 0; i < BR_PF; ++i) a_nxt[i] = mfma_a[(tb + BR_PF + i) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch up here: hipcc otherwise sinks it next to its first use
 #pragma unroll
-                for (int tt = 0; tt < BR_NT; ++tt) {
-                    const double m = bvmin(bvmin(acc[tt][0], acc[tt][1]), bvmin(acc[tt][2], acc[tt][3]));
-                    gm[tt] = (i == 0) ? m : bvmin(gm[tt], m);
+                for (int i = 0; i < BR_PF; ++i) {
+                    // tiles past t1 inside the last group belong to the next split or are padding: harmless to look at
+                    v4f64 cur[BR_NT];
+#pragma unroll
+                    for (int tt = 0; tt < BR_NT; ++tt) cur[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[i], bq[tt], cq[tt], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < BR_NT; ++tt) {
+                        const double m = bvmin(bvmin(acc[tt][0], acc[tt][1]), bvmin(acc[tt][2], acc[tt][3]));
+                        gm[tt] = (h == 0 && i == 0) ? m : bvmin(gm[tt], m);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < BR_NT; ++tt) acc[tt] = cur[tt];
                 }
 #pragma unroll
-                for (int tt = 0; tt < BR_NT; ++tt) acc[tt] = cur[tt];
+                for (int i = 0; i < BR_PF; ++i) a_cur[i] = a_nxt[i];
             }
             // one tracker update per group: smallest and second-smallest packed group minimum
 #pragma unroll
@@ -183,8 +194,6 @@ brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tg
                 sec[tt] = bvmin(sec[tt], bvmax(best[tt], p));
                 best[tt] = bvmin(best[tt], p);
             }
-#pragma unroll
-            for (int i = 0; i < BR_PF; ++i) a_cur[i] = a_nxt[i];
         }
 #pragma unroll
         for (int tt = 0; tt < BR_NT; ++tt) {  // the last tile is a group of its own; then unpack the winning group
@@ -195,7 +204,7 @@ brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tg
             bgrp[tt] = best[tt] < 1e299 ? (int)((unsigned int)__double2loint(best[tt]) & BR_CODE_MASK) : -1;
         }
     }
-    // exact re-evaluation of the winning group's rows (4 tiles x this lane's 4 rows), then merge the 4 row groups
+    // exact re-evaluation of the winning group's rows (BR_GRP tiles x this lane's 4 rows), then merge the 4 row groups
     const int rg = lane >> 4;
 #pragma unroll
     for (int tt = 0; tt < BR_NT; ++tt) {
@@ -205,8 +214,8 @@ brute_nn_kernel(const double* __restrict__ mfma_a, const pcr_pt* __restrict__ tg
         int bid = 0x7fffffff;
         double pamb = DBL_MAX;
         if (bgrp[tt] >= 0) {
-            const long long tl = t0 + 4ll * bgrp[tt] - 1;
-            for (int u = 0; u < BR_PF; ++u) {
+            const long long tl = t0 + (long long)BR_GRP * bgrp[tt] - 1;
+            for (int u = 0; u < BR_GRP; ++u) {
                 const long long tile = tl + u;
                 if (tile < t0) continue;
 #pragma unroll

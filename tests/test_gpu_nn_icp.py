@@ -201,7 +201,8 @@ def test_nn1_dense_volume_and_clustered_duplicates(pcp, oracle, kind):
     assert np.array_equal(d2, bd2)
     assert np.array_equal(idx, bi)  # np.argmin also returns the first (lowest) index on ties
     if kind == "brute":
-        # the 50 queries next to the 200 duplicates cannot be proven by the packed argmin: they took the exact sweep
+        # the 50 queries next to the 200 duplicates (12.5 consecutive tiles = at least two argmin groups of 8 tiles inside one
+        # target split of this launch) cannot be proven by the packed argmin: they took the exact sweep
         assert index.ctx.search_stats()["brute_fallback"] >= 50
 
 
