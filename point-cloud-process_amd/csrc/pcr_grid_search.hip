@@ -103,7 +103,11 @@ constexpr int WT_Q = PCR_WT_Q;      // queries per wave tile (16 or 32)
 #endif
 constexpr int WT_MAXC = PCR_WT_MAXC;        // cells in a wave-tile box (a 7 x 7 x 7 box = 64 two-cell blocks fits: the gate ball of a sparse-region query at 0.8 m cells)
 constexpr int WT_PR = 192;          // points staged per round (3 chunks of 64, loaded back to back)
-constexpr int WT_PASSES = 3;
+#ifndef PCR_WT_PASSES
+#define PCR_WT_PASSES 3
+#endif
+constexpr int WT_PASSES = PCR_WT_PASSES;
+constexpr int WT_PASSES_SEEDED = WT_PASSES < 2 ? WT_PASSES : 2;
 constexpr int WT_ROUNDS_SMALL = 4, WT_ROUNDS_LARGE = 12;
 
 struct wtile_lds {
@@ -271,8 +275,10 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
     }
     unsigned long long dbg_pairs = 0;
     unsigned int dbg_passes = 0;
+    // seeded tiles (ICP passes after the first) settle 97 % of their queries in pass 0; a third pass only feeds the kernel's tail
+    const int max_passes = prev_xyz ? WT_PASSES_SEEDED : WT_PASSES;
 #pragma unroll 1
-    for (int pass = 0; pass < WT_PASSES; ++pass) {
+    for (int pass = 0; pass < max_passes; ++pass) {
         const bool part = open && !clamped;
         if (!__any(part)) break;
         // ---- the cube every open query claims, in level-0 cell coordinates
