@@ -60,45 +60,63 @@ struct head_flag {  // position i starts a group of equal keys
     __host__ __device__ bool operator()(unsigned int i) const { return i == 0u || keys[i] != keys[i - 1u]; }
 };
 
-// NumPy pairwise_sum over a[k] = coord(pts[perm[start + k]]), k in [0, n)
+// NumPy pairwise_sum over a[k] = coord(pts[perm[start + k]]), k in [0, n), for the three coordinates AT ONCE: every
+// record is gathered once (not once per axis) and the 8 records of an unrolled step are requested together, so a dense
+// voxel costs n/8 dependent memory round trips instead of 3n.  Per axis the additions and their order are exactly
+// NumPy's (8 accumulators over blocks of <= 128, then the pairwise tree), so the centroids stay bitwise equal.
 struct coord_view {
     const pcr_pt* pts;
     const unsigned int* perm;
     unsigned int start;
-    int axis;
-    __device__ double at(unsigned int k) const {
-        const pcr_pt p = pts[perm[start + k]];
-        return axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
-    }
+    __device__ pcr_pt at(unsigned int k) const { return pts[perm[start + k]]; }
 };
 
-__device__ static double pw_leaf(const coord_view& a, unsigned int off, unsigned int n) {
+struct sum3 { double x, y, z; };
+
+__device__ static sum3 pw_leaf(const coord_view& a, unsigned int off, unsigned int n) {
     if (n < 8) {
-        double res = 0.0;
-        for (unsigned int i = 0; i < n; ++i) res += a.at(off + i);
+        sum3 res = {0.0, 0.0, 0.0};
+        for (unsigned int i = 0; i < n; ++i) {
+            const pcr_pt p = a.at(off + i);
+            res.x += p.x; res.y += p.y; res.z += p.z;
+        }
         return res;
     }
-    double r[8];
+    double rx[8], ry[8], rz[8];
+    {
+        pcr_pt p[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = a.at(off + j);
+        for (int j = 0; j < 8; ++j) p[j] = a.at(off + j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rx[j] = p[j].x; ry[j] = p[j].y; rz[j] = p[j].z; }
+    }
     unsigned int i = 8;
     for (; i < n - (n % 8); i += 8) {
+        pcr_pt p[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] += a.at(off + i + j);
+        for (int j = 0; j < 8; ++j) p[j] = a.at(off + i + j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rx[j] += p[j].x; ry[j] += p[j].y; rz[j] += p[j].z; }
     }
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res += a.at(off + i);
+    sum3 res;
+    res.x = ((rx[0] + rx[1]) + (rx[2] + rx[3])) + ((rx[4] + rx[5]) + (rx[6] + rx[7]));
+    res.y = ((ry[0] + ry[1]) + (ry[2] + ry[3])) + ((ry[4] + ry[5]) + (ry[6] + ry[7]));
+    res.z = ((rz[0] + rz[1]) + (rz[2] + rz[3])) + ((rz[4] + rz[5]) + (rz[6] + rz[7]));
+    for (; i < n; ++i) {
+        const pcr_pt p = a.at(off + i);
+        res.x += p.x; res.y += p.y; res.z += p.z;
+    }
     return res;
 }
 
-__device__ static double numpy_pairwise_sum(const coord_view& a, unsigned int n) {
+__device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int n) {
     if (n <= 128) return pw_leaf(a, 0, n);
     // explicit stack for: sum(off, n) = n <= 128 ? leaf : sum(off, n2) + sum(off + n2, n - n2), n2 = (n/2) rounded down to 8
-    struct frame { unsigned int off, n; int state; double left; };
+    struct frame { unsigned int off, n; int state; sum3 left; };
     frame st[40];
     int sp = 0;
-    st[sp++] = {0u, n, 0, 0.0};
-    double ret = 0.0;
+    st[sp++] = {0u, n, 0, {0.0, 0.0, 0.0}};
+    sum3 ret = {0.0, 0.0, 0.0};
     while (sp > 0) {
         frame& f = st[sp - 1];
         if (f.n <= 128) {
@@ -110,13 +128,13 @@ __device__ static double numpy_pairwise_sum(const coord_view& a, unsigned int n)
         n2 -= n2 % 8;
         if (f.state == 0) {
             f.state = 1;
-            st[sp++] = {f.off, n2, 0, 0.0};
+            st[sp++] = {f.off, n2, 0, {0.0, 0.0, 0.0}};
         } else if (f.state == 1) {
             f.left = ret;
             f.state = 2;
-            st[sp++] = {f.off + n2, f.n - n2, 0, 0.0};
+            st[sp++] = {f.off + n2, f.n - n2, 0, {0.0, 0.0, 0.0}};
         } else {
-            ret = f.left + ret;
+            ret.x = f.left.x + ret.x; ret.y = f.left.y + ret.y; ret.z = f.left.z + ret.z;
             --sp;
         }
     }
@@ -149,12 +167,9 @@ __global__ void voxel_emit_kernel(const pcr_pt* __restrict__ pts, const unsigned
         }
         ox /= (double)cnt; oy /= (double)cnt; oz /= (double)cnt;
     } else if (mode == 0) {
-        coord_view a{pts, perm, s, 0};
-        ox = numpy_pairwise_sum(a, cnt) / (double)cnt;
-        a.axis = 1;
-        oy = numpy_pairwise_sum(a, cnt) / (double)cnt;
-        a.axis = 2;
-        oz = numpy_pairwise_sum(a, cnt) / (double)cnt;
+        const coord_view a{pts, perm, s};
+        const sum3 t = numpy_pairwise_sum(a, cnt);
+        ox = t.x / (double)cnt; oy = t.y / (double)cnt; oz = t.z / (double)cnt;
     } else {
         const unsigned int k = (unsigned int)(splitmix64(seed ^ ((unsigned long long)v * 0xD1B54A32D192ED03ull)) % cnt);
         const pcr_pt p = pts[perm[s + k]];
