@@ -348,7 +348,7 @@ def main():
         ctx.profile(False)
         kern = {}
         if a.nn == "grid":
-            names = ["grid_wtile_kernel", "grid_hard_kernel", "grid_accumulate_kernel", "-"]
+            names = ["grid_wtile_kernel", "grid_hard_kernel", "-", "-"]   # the hard-stage launch also accumulates, solves and tests (fused)
         else:
             names = ["brute_nn_kernel", "brute_merge_kernel+brute_exact_kernel", "brute_final_kernel", "brute_reduce_partials_kernel"]
         for nm, ms in zip(names, prof_ms):

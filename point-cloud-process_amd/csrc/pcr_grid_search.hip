@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT
 grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
                   int gated, int xcd_remap, unsigned int pcap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2,
                   work_item* __restrict__ hard_list, unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg,
-                  const pcr_icp_dev_state* __restrict__ st, const wt_xyz* __restrict__ prev_xyz) {
+                  const pcr_icp_dev_state* __restrict__ st, const wt_xyz* __restrict__ prev_xyz, unsigned int* __restrict__ open_mask) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ wtile_lds s_lds[4];
@@ -551,6 +551,7 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
     // ---- what is still open goes to the hard stage: one append per wave
     const bool unres = open && lane < WT_Q;
     const unsigned long long m = __ballot(unres);
+    if (open_mask && lane == 0) open_mask[(size_t)blk * 4 + wave] = (unsigned int)m;   // which of the tile's queries the hard stage owns
     if (m) {
         const unsigned int n_unres = __popcll(m);
         unsigned int base = 0;
@@ -586,6 +587,54 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
             for (int i = 0; i < 8; ++i) dbg[(1 << 16) + blockIdx.x * 8 + i] = t_ph[i];
 #endif
     }
+}
+
+// ------------------------------------------------------------- moments
+// one gated correspondence into the 19 running Procrustes moments about `origin` (same arithmetic everywhere it is used)
+__device__ static inline void moments_add(double* __restrict__ m, const double origin[3], double ax, double ay, double az, const pcr_pt& b,
+                                          double max_d2, int gated) {
+    const double d2 = dist2(ax, ay, az, b);
+    if (gated && !(d2 < max_d2)) return;
+    const double a0 = ax - origin[0], a1 = ay - origin[1], a2 = az - origin[2];
+    const double b0 = b.x - origin[0], b1 = b.y - origin[1], b2 = b.z - origin[2];
+    m[0] += 1.0;
+    m[1] += a0; m[2] += a1; m[3] += a2;
+    m[4] += b0; m[5] += b1; m[6] += b2;
+    m[7] += b0 * a0; m[8] += b0 * a1; m[9] += b0 * a2;
+    m[10] += b1 * a0; m[11] += b1 * a1; m[12] += b1 * a2;
+    m[13] += b2 * a0; m[14] += b2 * a1; m[15] += b2 * a2;
+    m[16] += (a0 * a0 + a1 * a1) + a2 * a2;
+    m[17] += (b0 * b0 + b1 * b1) + b2 * b2;
+    m[18] += d2;
+}
+
+// Fused hard stage + accumulation of the device-resident ICP loop.  Partial moments meet in 64-bit FIXED-POINT
+// accumulators (value * 2^F, F chosen on the host so that N * R^2 * 2^F < 2^61): integer additions commute, so
+// any number of waves may add in any order -- atomics, no slabs, no second kernel -- and the totals are still bitwise
+// reproducible.  Each wave total / hard item is rounded to 2^-F once (<= (waves + items) * 2^-F on a sum bounded by
+// N R^2: ~1e-14 relative, two orders above binary64 round-off and five below the parity bar).
+// Accumulator sets: atomics to one cache line serialise at its L2 channel (~100 ns each), so the ~60 000 atomics of a pass are
+// spread over 1024 sets = 2 560 lines (64 sets measured 52 us for the fused kernel, i.e. ~35 us of queued atomics)
+#ifndef PCR_ACC_SETS
+#define PCR_ACC_SETS 64
+#endif
+constexpr int ACC_SETS = PCR_ACC_SETS;
+struct hard_acc_args {
+    int acc_blocks;                       // 0: plain hard stage (nn1 API, host loop)
+    const pcr_pt* q;                      // the source, already transformed in place by the tile kernel
+    const unsigned int* open_mask;        // per wave tile: which queries the hard stage owns
+    unsigned long long* acc;              // [ACC_SETS][PCR_NMOM], zero on entry, zeroed again by the finishing block
+    unsigned int* ticket;
+    wt_xyz* prev_xyz;
+    double scale, inv_scale;              // 2^F, 2^-F
+    pcr_icp_dev_state* st;
+    pcr_icp_loop_args la;
+};
+
+// lanes 0..18 of the calling wave add one moment each (one vector atomic instruction); mk = this lane's moment
+__device__ static inline void acc_fixed_add(unsigned long long* __restrict__ acc, unsigned int set, int lane, double mk, double scale) {
+    if (lane < PCR_NMOM - 1 && mk != 0.0)
+        atomicAdd(acc + (size_t)(set % ACC_SETS) * PCR_NMOM + lane, (unsigned long long)__double2ll_rn(mk * scale));   // two's complement
 }
 
 // -------------------------------------------------------------- hard stage
@@ -714,11 +763,55 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
 __global__ void __launch_bounds__(256)
 grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ count_p, long long nq, double max_d2, int gated,
                  unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, unsigned long long* __restrict__ dbg,
-                 const pcr_icp_dev_state* __restrict__ st) {
+                 const pcr_icp_dev_state* __restrict__ st, hard_acc_args A) {
     __shared__ hard_lds s_lds[4];
     if (st && st->stop) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     hard_lds* L = &s_lds[wave];
+    if ((int)blockIdx.x < A.acc_blocks) {
+        // Phase P: the moments of the queries the wave tiles PROVED (their open_mask bit is clear), four per thread; they do
+        // not depend on the hard stage, so they are accumulated while the other blocks already walk the hard lists
+        double m[PCR_NMOM];
+#pragma unroll
+        for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+        const long long stride = (long long)A.acc_blocks * blockDim.x;
+        for (long long q0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < nq; q0 += 4 * stride) {
+            unsigned int pos[4];
+            pcr_pt p[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long qi = q0 + u * stride;
+                pos[u] = POS_NONE;
+                if (qi < nq) {
+                    const unsigned int mk = A.open_mask[qi / WT_Q];
+                    if (!((mk >> (unsigned int)(qi % WT_Q)) & 1u)) pos[u] = res_pos[qi];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long qi = q0 + u * stride;
+                if (qi < nq) p[u] = A.q[qi];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pos[u] != POS_NONE) b[u] = gv.pts[pos[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (pos[u] == POS_NONE) continue;
+                A.prev_xyz[q0 + u * stride] = wt_xyz{b[u].x, b[u].y, b[u].z};   // seed of the next pass's wave tiles
+                moments_add(m, gv.origin, p[u].x, p[u].y, p[u].z, b[u], max_d2, gated);
+            }
+        }
+        double* xch = reinterpret_cast<double*>(L);   // this wave's LDS slice: 19 totals from lane 63 to lanes 0..18
+#pragma unroll
+        for (int k = 0; k < PCR_NMOM - 1; ++k) {
+            const double tot = wave_total_f64(m[k]);   // fixed order inside the wave
+            if (lane == 63) xch[k] = tot;
+        }
+        wave_sync();
+        acc_fixed_add(A.acc, blockIdx.x * 4u + (unsigned int)wave, lane, lane < PCR_NMOM - 1 ? xch[lane] : 0.0, A.scale);
+        wave_sync();
+    }
     // exclusive prefix of the sub-list lengths (lanes 0..H_NLIST-1 hold one list each)
     unsigned int l_cnt = lane < H_NLIST ? count_p[H_CSTRIDE * lane] : 0u;
     unsigned int l_inc = l_cnt;
@@ -731,7 +824,10 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
     const unsigned int l_exc = l_inc - l_cnt;
     const unsigned int l_cap = hard_list_cap(nq);
     const int top = gv.levels - 1;
-    for (unsigned int w = blockIdx.x * 4 + wave; w < count; w += gridDim.x * 4) {
+    // (the blocks that accumulated the proven queries above do not take hard items: they would start them ~6 us late and
+    // become the kernel's tail)
+    const unsigned int hgrid = gridDim.x - (unsigned int)A.acc_blocks;
+    for (unsigned int w = ((int)blockIdx.x < A.acc_blocks ? count : (blockIdx.x - (unsigned int)A.acc_blocks) * 4 + wave); w < count; w += hgrid * 4) {
         const int hl = (int)__ffsll((long long)__ballot(lane < H_NLIST && l_exc <= w && w < l_exc + l_cnt)) - 1;  // exactly one list holds item w
         const work_item it = list[(size_t)hl * l_cap + (w - __shfl(l_exc, hl, 64))];
         const unsigned long long h_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -847,6 +943,22 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
             const unsigned int opos = __shfl_xor(bpos, off, 64);
             if (better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; bpos = opos; }
         }
+        if (A.acc && bpos != POS_NONE) {   // wave-uniform: after the merge every lane holds the same result
+            double* xch = reinterpret_cast<double*>(L->fl_off);   // 19 moments from lane 0 to lanes 0..18 (fl_off/fl_start: 512 B, free here)
+            if (lane == 0) {
+                const pcr_pt b = gv.pts[bpos];
+                A.prev_xyz[it.qi] = wt_xyz{b.x, b.y, b.z};
+                double m[PCR_NMOM];
+#pragma unroll
+                for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+                moments_add(m, gv.origin, ax, ay, az, b, max_d2, gated);
+#pragma unroll
+                for (int k = 0; k < PCR_NMOM - 1; ++k) xch[k] = m[k];
+            }
+            wave_sync();
+            acc_fixed_add(A.acc, w, lane, lane < PCR_NMOM - 1 ? xch[lane] : 0.0, A.scale);
+            wave_sync();
+        }
         if (lane == 0) {
             res_pos[it.qi] = bpos;
             if (res_d2) res_d2[it.qi] = bd2;
@@ -858,6 +970,63 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
             }
         }
     }
+    if (!A.acc) return;
+    // ---- the block that arrives last converts the totals, solves the Procrustes step and tests convergence.
+    // Hand-off: the only data the finishing block reads from other blocks are the accumulators, and those are touched by
+    // device-scope atomics alone (performed at the coherence point, no cache to flush).  So a block only waits for its own
+    // atomics to be acknowledged (vmcnt) and takes a ticket with a relaxed atomic -- NO agent-scope release fence: on this
+    // chip that fence writes back the XCD's L2, and 2048 blocks doing it cost 40 us.  (res_pos / prev_xyz stores are for the
+    // NEXT kernel; the kernel boundary publishes them.)
+    __shared__ unsigned int s_last;
+    __shared__ double s_m[PCR_NMOM];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // two-level ticket: a returning atomic on ONE word serialises at ~88 per us (2048 blocks: 23 us).  Block b takes a
+        // ticket of group b % 32 (64 bytes apart); the last arriver of a group takes one of the root ticket; the last of those finishes.
+        const unsigned int ngroups = gridDim.x < 32u ? gridDim.x : 32u;
+        const unsigned int g = blockIdx.x % ngroups;
+        const unsigned int gsize = gridDim.x / ngroups + (g < gridDim.x % ngroups ? 1u : 0u);
+        unsigned int* gt = A.ticket + 16u * (1u + g);
+        s_last = 0u;
+        if (__hip_atomic_fetch_add(gt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+            __hip_atomic_store(gt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) {
+                s_last = 1u;
+                __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < H_NLIST) const_cast<unsigned int*>(count_p)[H_CSTRIDE * threadIdx.x] = 0;   // next search starts with empty lists
+    // ACC_SETS x 20 words: independent loads, 8 per thread and step, summed as integers (order irrelevant), zeroed for the next pass
+    __shared__ unsigned long long s_tot[PCR_NMOM];
+    if (threadIdx.x < PCR_NMOM) s_tot[threadIdx.x] = 0ull;
+    __syncthreads();
+    {
+        // thread t owns words t, t + 256, ...; 256 = 12 * 20 + 16, so a thread's moment index walks through all 20 values:
+        // keep one running sum per thread and moment residue instead -> simpler: add every word to its LDS total
+        constexpr int WORDS = ACC_SETS * PCR_NMOM;
+        for (int i0 = threadIdx.x; i0 < WORDS; i0 += 256 * 8) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)   // device-scope atomic loads: the words were only ever written by device-scope atomics
+                v[j] = (i0 + 256 * j < WORDS) ? __hip_atomic_load(A.acc + i0 + 256 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + 256 * j;
+                if (v[j]) {
+                    __hip_atomic_store(A.acc + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(&s_tot[i % PCR_NMOM], v[j]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < PCR_NMOM) s_m[threadIdx.x] = (double)(long long)s_tot[threadIdx.x] * A.inv_scale;
+    __syncthreads();
+    if (threadIdx.x == 0) pcr::icp_step(A.st, s_m, gv.origin, A.la);
 }
 
 // --------------------------------------------------------------- epilogues
@@ -1008,6 +1177,8 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
 struct grid_scratch {
     unsigned int* res_pos = nullptr;
     double* res_d2 = nullptr;
+    unsigned int* open_mask = nullptr;  // [wave tiles]: bit i = query i of the tile went to the hard stage (device loop only)
+    unsigned long long* acc = nullptr;  // [ACC_SETS][PCR_NMOM] fixed-point moment accumulators (device loop only)
     void* prev_xyz = nullptr;         // [nq] x 24 B: coordinates of every query's neighbour of the last ICP pass (device loop only)
     work_item* hard_list = nullptr;   // [nq] worst case
     unsigned int* hard_count = nullptr;
@@ -1038,13 +1209,16 @@ static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
     if (sc->res_d2) pcr_dev_free(ctx, sc->res_d2, sizeof(double) * sc->nq);
     if (sc->hard_list) pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(sc->nq));
     if (sc->prev_xyz) pcr_dev_free(ctx, sc->prev_xyz, 24 * (size_t)sc->nq);
-    sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr; sc->prev_xyz = nullptr;
+    if (sc->open_mask) pcr_dev_free(ctx, sc->open_mask, sizeof(unsigned int) * (size_t)((sc->nq + WT_Q - 1) / WT_Q + 4));
+    if (sc->acc) pcr_dev_free(ctx, sc->acc, sizeof(unsigned long long) * ACC_SETS * PCR_NMOM);
+    sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr; sc->prev_xyz = nullptr; sc->open_mask = nullptr; sc->acc = nullptr;
 }
 
 // Enqueues the search stages on `stream` over the `nq` records at `q` (a whole Morton-sorted cloud or a run of it);
 // leaves res_pos (and res_d2 when the scratch has it) on the device.  `st` != null: device-resident ICP loop.
 static int grid_search_enqueue(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, hipStream_t stream, const pcr_xform* x, int write_back,
-                               double max_d2, bool gated, bool mark, grid_scratch* sc, const pcr_icp_dev_state* st, bool use_prev = false) {
+                               double max_d2, bool gated, bool mark, grid_scratch* sc, const pcr_icp_dev_state* st, bool use_prev = false,
+                               const hard_acc_args* acc = nullptr) {
     const int nblocks = (int)((nq + 63) / 64);
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
@@ -1057,15 +1231,16 @@ static int grid_search_enqueue(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, in
         const int wblocks = (int)((nq + 4 * WT_Q - 1) / (4 * WT_Q));
         hipLaunchKernelGGL(grid_wtile_kernel, dim3(wblocks), dim3(256), 0, stream, (const pcr_grid_view*)idx->d_view, q, (long long)nq, x ? *x : xi, (x || st) ? 1 : 0,
                            write_back, max_d2, gated ? 1 : 0, xcd_remap, wpcap, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug, st,
-                           (const wt_xyz*)(use_prev ? sc->prev_xyz : nullptr));
+                           (const wt_xyz*)(use_prev ? sc->prev_xyz : nullptr), acc ? sc->open_mask : nullptr);
     }
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;
     // 8 blocks of 4 waves per CU: twice what is resident at 4 waves per SIMD (4 x CU measured the same, 2 x CU 30 % slower)
     const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
-    hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, stream, idx->view, (const work_item*)sc->hard_list,
-                       (const unsigned int*)sc->hard_count, (long long)nq, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug, st);
+    hipLaunchKernelGGL(grid_hard_kernel, dim3(g3 + (acc ? acc->acc_blocks : 0)), dim3(256), 0, stream, idx->view, (const work_item*)sc->hard_list,
+                       (const unsigned int*)sc->hard_count, (long long)nq, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug, st,
+                       acc ? *acc : hard_acc_args{});
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
@@ -1198,12 +1373,39 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     const int64_t nq = qc->n;
     grid_scratch sc;
     if ((rc = grid_scratch_alloc(ctx, nq, false, ctx->d_counters + PCR_HARD_COUNTERS, &sc))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, 24 * (size_t)nq, &sc.prev_xyz))) {
+    const int n_wtiles = (int)((nq + WT_Q - 1) / WT_Q);
+    if ((rc = pcr_dev_alloc(ctx, 24 * (size_t)nq, &sc.prev_xyz)) ||
+        (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (size_t)(n_wtiles + 4), (void**)&sc.open_mask)) ||
+        (rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * ACC_SETS * PCR_NMOM, (void**)&sc.acc))) {
         grid_scratch_free(ctx, &sc);
         return rc;
     }
     int grid = (int)((nq + 1023) / 1024);  // four queries per thread
     if (grid > ctx->cu_count) grid = ctx->cu_count;
+    // Fused hard stage + accumulation (fixed-point accumulators): needs a gate (it bounds |a'| by the target's extent) and
+    // enough fraction bits.  Every moment is bounded by M = N * max(R^2, gate, 1), R = half diagonal of the target box + gate radius.
+    hard_acc_args acc_args{};
+    bool fused = gated && getenv("PCR_ICP_NO_FUSED") == nullptr;
+    if (fused) {
+        double r2 = 0.0;
+        for (int k = 0; k < 3; ++k) r2 += 0.25 * (idx->hi[k] - idx->lo[k]) * (idx->hi[k] - idx->lo[k]);
+        const double R = sqrt(r2) + sqrt(params->max_d2);
+        const double M = (double)nq * fmax(fmax(R * R, params->max_d2), 1.0);
+        int ex = 0;
+        frexp(M, &ex);              // M < 2^ex
+        const int F = 61 - ex;
+        if (!(M > 0) || !std::isfinite(M) || F < 20) fused = false;   // absurd extents: keep the binary64 slabs
+        else {
+            acc_args.acc_blocks = grid;
+            acc_args.q = qc->d;
+            acc_args.open_mask = sc.open_mask;
+            acc_args.acc = sc.acc;
+            acc_args.ticket = ctx->d_counters + 256;   // root ticket + 32 group tickets, 64 bytes apart (words 256..783)
+            acc_args.prev_xyz = (wt_xyz*)sc.prev_xyz;
+            acc_args.scale = ldexp(1.0, F);
+            acc_args.inv_scale = ldexp(1.0, -F);
+        }
+    }
     pcr_icp_dev_state* d_st = nullptr;
     if ((rc = pcr_ensure_scratch(ctx, sizeof(double) * PCR_NMOM * (size_t)grid)) ||
         (rc = pcr_dev_alloc(ctx, sizeof(pcr_icp_dev_state), (void**)&d_st))) {
@@ -1226,6 +1428,9 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     la.compat = params->mode == PCR_ICP_COMPAT_MAIN; la.r_metric = params->r_metric;
     la.r_thres = params->r_thres; la.t_thres = params->t_thres;
     hipError_t e = hipMemcpyAsync(d_st, h_st, sizeof(*h_st), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && fused) e = hipMemsetAsync(sc.acc, 0, sizeof(unsigned long long) * ACC_SETS * PCR_NMOM, ctx->stream);
+    acc_args.st = d_st;
+    acc_args.la = la;
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
     int enq = 0, launches = 0;
@@ -1239,13 +1444,17 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         for (int c = 0; c < chunk && rc == PCR_OK; ++c) {
             // from the second pass on, res_pos holds the previous pass's neighbours (same query order, same target)
             static const bool no_prev = getenv("PCR_NO_PREV") != nullptr;
-            rc = grid_search_enqueue(ctx, idx, qc->d, nq, ctx->stream, nullptr, 1, params->max_d2, gated, ctx->profile, &sc, d_st, enq + c > 0 && !no_prev);
+            rc = grid_search_enqueue(ctx, idx, qc->d, nq, ctx->stream, nullptr, 1, params->max_d2, gated, ctx->profile, &sc, d_st, enq + c > 0 && !no_prev,
+                                     fused ? &acc_args : nullptr);
             if (rc) break;
             pcr_prof_mark(ctx, 2);
-            // after the write-back of the tile kernel the cloud already holds the transformed points
-            hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, xi,
-                               0, (const unsigned int*)sc.res_pos, params->max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
-                               (double*)nullptr, sc.hard_count, d_st, la, (wt_xyz*)sc.prev_xyz);
+            if (!fused) {
+                // (ungated or absurdly large clouds) binary64 slabs: after the write-back of the tile kernel the cloud already
+                // holds the transformed points
+                hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, xi,
+                                   0, (const unsigned int*)sc.res_pos, params->max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
+                                   (double*)nullptr, sc.hard_count, d_st, la, (wt_xyz*)sc.prev_xyz);
+            }
             pcr_prof_mark(ctx, 3);
             pcr_prof_mark(ctx, 4);
             pcr_prof_finish(ctx);   // per-kernel HIP events (profiling only: one event sync per pass)
