@@ -66,7 +66,7 @@ def gpu_register_fn(device=0, nn="grid", mode="compat", streams=1, **icp_kw):
     return run
 
 
-def register_batch(pairs, register_fn=None, group=None, device=None, streams=4, **kw):
+def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, **kw):
     """Register ``pairs`` = sequence of (src (N,3+), tgt (M,3+), T0 or None).
 
     Without torch.distributed (or world size 1) everything runs on this process's GPU.  Inside an
