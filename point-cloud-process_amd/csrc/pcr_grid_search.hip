@@ -836,13 +836,9 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
         double bd2 = DBL_MAX;
         long long bid = ID_NONE;
         unsigned int bpos = POS_NONE;
-        if (lane == 0 && it.best_pos != POS_NONE) {
-            // it.best_d2 is only an upper bound of this candidate's distance (see the tile stage): take the exact one
-            bpos = it.best_pos;
-            const pcr_pt b0 = gv.pts[bpos];
-            bd2 = dist2(ax, ay, az, b0);
-            bid = b0.id;
-        }
+        // it.best_d2 is an UPPER bound of the tile stage's candidate's squared distance: it bounds the search, and the candidate
+        // itself is met again by the scan (it lies inside the bound) -- reading its record here would be one more dependent
+        // memory round trip in a chain of four
         double bound2 = gated ? fmin(it.best_d2, max_d2) : it.best_d2;  // DBL_MAX when nothing bounds the search
         bool clamped = false;
         const int cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
@@ -869,7 +865,7 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
             }
             return top + 1;  // not even the top level's block covers the ball
         };
-        const bool have_cand = __any(bd2 < DBL_MAX);
+        const bool have_cand = it.best_pos != POS_NONE || __any(bd2 < DBL_MAX);
         int s_level = clamped ? top + 1 : (have_cand ? level_for(bound2, 0) : 0);
         const int s_level0 = s_level;
         int sp = 0;  // wave-uniform stack pointer
