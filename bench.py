@@ -242,6 +242,9 @@ def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
         iters = np.array([r["iters"] for r in res])
         errs = [float(np.linalg.norm(res[i]["T"] - truth[i])) for i in truth] if tag == "tight" else []
         out[tag] = {"seconds": el, "pairs_per_s": BATCH_PAIRS / el, "pairs_per_s_per_gpu": BATCH_PAIRS / el / world,
+                    # both clouds of every pair as 16-B records over the wall time, against N x 8 TB/s: this block is
+                    # bound by per-pair host work (uploads, index build, synchronisations), not by HBM
+                    "hbm_frac_algorithmic": BATCH_PAIRS * 2 * BATCH_POINTS * 16 / el / (HBM_PEAK_GBS * 1e9 * world),
                     "correspondences_per_s": float(iters.sum()) * BATCH_POINTS / el, "mean_iters": float(iters.mean()),
                     "results_gathered": len(res)}
         if errs:
