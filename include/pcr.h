@@ -148,6 +148,26 @@ PCR_API void pcr_icp_default_params(pcr_icp_params* p);
 PCR_API int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* target_index, const pcr_icp_params* params,
                     const double T0[16], pcr_icp_result* result);
 
+/* Batched scan-pair registration: the loop Registration/main.py:190-216 (read pair, register, keep the pose) for many
+ * independent pairs at once.  pairs[i] are caller-owned host buffers (records of `stride` values, x,y,z first: stride 6 is
+ * the registration_dataset .bin record of main.py:10-17, stride 4 the KITTI record); T0 may be NULL (identity).
+ * The n_ctx contexts (one device, one HIP stream each) are driven by n_ctx native worker threads that take pairs from a
+ * shared counter: upload both clouds, build the grid index, run pcr_icp, free -- several pairs in flight per GPU, no
+ * interpreter in the loop.  results[i] belongs to pairs[i] whatever thread ran it; status_out[i] is pcr_icp's return
+ * value for that pair.  Returns the first hard error (< 0) or PCR_OK.  The contexts must not be used concurrently
+ * by the caller. */
+typedef struct pcr_pair {
+    const float* src;     /* n_src records of stride_src floats */
+    int64_t n_src;
+    int64_t stride_src;
+    const float* tgt;
+    int64_t n_tgt;
+    int64_t stride_tgt;
+    const double* T0;     /* 16 doubles, row-major, or NULL */
+} pcr_pair;
+PCR_API int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_t n_pairs, const pcr_icp_params* params,
+                          pcr_icp_result* results, int32_t* status_out);
+
 /* One association + accumulation pass (no solve): the 18 moments the Procrustes
  * step needs: {K, Sa[3], Sb[3], Sba[9] (row-major b_i*a_j), Saa, Sbb}, taken about
  * `origin_out[3]`.  Lets tests check the fused kernel against the oracle.      */

@@ -72,6 +72,18 @@ class RansacResult(C.Structure):
     ]
 
 
+class Pair(C.Structure):
+    _fields_ = [
+        ("src", C.POINTER(C.c_float)),
+        ("n_src", C.c_int64),
+        ("stride_src", C.c_int64),
+        ("tgt", C.POINTER(C.c_float)),
+        ("n_tgt", C.c_int64),
+        ("stride_tgt", C.c_int64),
+        ("T0", C.POINTER(C.c_double)),
+    ]
+
+
 class IcpResult(C.Structure):
     _fields_ = [
         ("T", C.c_double * 16),
@@ -122,6 +134,7 @@ SIGNATURES = {
     "pcr_radius": (C.c_int, [_vp, _vp, _dp, C.c_int64, C.c_double, _lp, _lp, _ip, _dp]),
     "pcr_icp_default_params": (None, [C.POINTER(IcpParams)]),
     "pcr_icp": (C.c_int, [_vp, _vp, _vp, C.POINTER(IcpParams), _dp, C.POINTER(IcpResult)]),
+    "pcr_icp_batch": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(Pair), C.c_int64, C.POINTER(IcpParams), C.POINTER(IcpResult), _ip]),
     "pcr_icp_moments": (C.c_int, [_vp, _vp, _vp, _dp, C.c_double, _dp, _dp, _dp]),
     "pcr_procrustes": (C.c_int, [_dp, _dp, C.c_int64, _dp, _dp, _dp]),
     "pcr_homo2tq": (C.c_int, [_dp, _dp]),

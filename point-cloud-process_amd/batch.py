@@ -66,6 +66,56 @@ def gpu_register_fn(device=0, nn="grid", mode="compat", streams=1, **icp_kw):
     return run
 
 
+def native_register_share(pairs, device=0, streams=8, mode="compat", max_iter=100, r_thres=0.5, t_thres=0.5, max_d2=5.0,
+                          r_metric="frobenius", min_iter=0, nn="grid"):
+    """The local share of a batch through ONE C call (pcr_icp_batch): `streams` contexts on `device`, driven by native
+    worker threads that take pairs from a shared counter -- upload, index build, ICP, free, no interpreter in the loop.
+    `pairs`: (src (N,>=3) float32, tgt (M,>=3) float32, T0 or None).  Returns result dicts in input order."""
+    import ctypes as C
+
+    from . import _lib as L
+    from .device import Context
+
+    if nn != "grid":
+        raise ValueError("the native batch path uses the grid index")
+    n = len(pairs)
+    if n == 0:
+        return []
+    ctxs = [Context(device) for _ in range(max(1, min(int(streams), n)))]
+    try:
+        arr = (L.Pair * n)()
+        keep = []
+        for i, (src, tgt, T0) in enumerate(pairs):
+            s = np.ascontiguousarray(src, dtype=np.float32)
+            t = np.ascontiguousarray(tgt, dtype=np.float32)
+            if s.ndim != 2 or t.ndim != 2 or s.shape[1] < 3 or t.shape[1] < 3:
+                raise ValueError("pairs must hold (N, >= 3) arrays")
+            keep += [s, t]
+            arr[i].src = s.ctypes.data_as(C.POINTER(C.c_float))
+            arr[i].n_src, arr[i].stride_src = s.shape[0], s.shape[1]
+            arr[i].tgt = t.ctypes.data_as(C.POINTER(C.c_float))
+            arr[i].n_tgt, arr[i].stride_tgt = t.shape[0], t.shape[1]
+            if T0 is not None:
+                T0c = L.as_f64(T0).reshape(16)
+                keep.append(T0c)
+                arr[i].T0 = L.dptr(T0c)
+        p = L.IcpParams()
+        L.lib().pcr_icp_default_params(C.byref(p))
+        p.max_iter, p.r_thres, p.t_thres, p.max_d2, p.min_iter = int(max_iter), float(r_thres), float(t_thres), float(max_d2), int(min_iter)
+        p.mode = L.PCR_ICP_COMPAT_MAIN if mode == "compat" else L.PCR_ICP_TOTAL
+        p.r_metric = L.PCR_RMETRIC_GEODESIC if r_metric == "geodesic" else L.PCR_RMETRIC_FROBENIUS
+        res = (L.IcpResult * n)()
+        status = np.zeros(n, dtype=np.int32)
+        handles = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+        rc = L.lib().pcr_icp_batch(handles, len(ctxs), arr, n, C.byref(p), res, L.iptr(status))
+        L.check(rc, ctxs[0].handle)
+        return [{"T": np.array(r.T[:]).reshape(4, 4), "T_total": np.array(r.T_total[:]).reshape(4, 4), "iters": r.iters, "status": r.status,
+                 "n_assoc": r.n_assoc, "cost": r.cost, "mean_d2": r.mean_d2} for r in res]
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, **kw):
     """Register ``pairs`` = sequence of (src (N,3+), tgt (M,3+), T0 or None).
 
@@ -87,12 +137,18 @@ def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, 
         dist = None
     n = len(pairs)
     lo, hi = shard_range(n, rank, world)
+    native = False
     if register_fn is None:
         if device is None:
             import os
 
             device = int(os.environ.get("LOCAL_RANK", "0"))
-        register_fn = gpu_register_fn(device=device, streams=streams, **kw)
+        # float32 records (what the dataset readers return) go through the native batch entry point; anything else (float64
+        # clouds, the brute-force index) through the per-pair Python worker
+        native = kw.get("nn", "grid") == "grid" and all(
+            np.asarray(pairs[i][0]).dtype == np.float32 and np.asarray(pairs[i][1]).dtype == np.float32 for i in range(lo, hi))
+        if not native:
+            register_fn = gpu_register_fn(device=device, streams=streams, **kw)
     workers = int(getattr(register_fn, "streams", 1))
     local = np.zeros((hi - lo, RECORD))
     # A pcr_ctx is not thread-safe: a slot (= one context, one HIP stream) belongs to exactly one task at a time.
@@ -111,7 +167,10 @@ def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, 
             slots.put(slot)
         local[i - lo] = pack_result(i, res)
 
-    if workers > 1 and hi - lo > 1:
+    if native:
+        for j, res in enumerate(native_register_share([pairs[i] for i in range(lo, hi)], device=device, streams=streams, **kw)):
+            local[j] = pack_result(lo + j, res)
+    elif workers > 1 and hi - lo > 1:
         with ThreadPoolExecutor(max_workers=workers) as pool:
             list(pool.map(one, range(lo, hi)))
     else:
@@ -126,7 +185,7 @@ def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, 
     use_cuda = dist.get_backend(group) == "nccl"
     if use_cuda:
         # the gather buffer lives on the SAME device as this rank's pcr contexts (not on whatever torch's current device is)
-        dev_id = getattr(register_fn, "device", device)
+        dev_id = getattr(register_fn, "device", device) if register_fn is not None else device
         if dev_id is None:
             import os
 

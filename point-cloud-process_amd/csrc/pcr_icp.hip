@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "pcr_internal.h"
 #include "pcr_linalg.h"
@@ -190,6 +192,46 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
     hipEventElapsedTime(&loop_ms, ctx->ev0, ctx->ev1);
     res->device_ms = loop_ms;
     return res->status;
+}
+
+int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_t n_pairs, const pcr_icp_params* params,
+                  pcr_icp_result* results, int32_t* status_out) {
+    if (!ctxs || n_ctx <= 0 || (n_pairs > 0 && (!pairs || !results)) || !params) return PCR_E_INVALID;
+    for (int c = 0; c < n_ctx; ++c)
+        if (!ctxs[c]) return PCR_E_INVALID;
+    std::atomic<int64_t> next(0);
+    std::atomic<int> hard_error(PCR_OK);
+    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    auto worker = [&](pcr_ctx* ctx) {
+        hipSetDevice(ctx->device);
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= n_pairs || hard_error.load() != PCR_OK) break;
+            const pcr_pair& P = pairs[i];
+            pcr_cloud *src = nullptr, *tgt = nullptr;
+            pcr_index* index = nullptr;
+            int rc = pcr_cloud_upload_f32(ctx, P.src, P.n_src, P.stride_src, &src);
+            if (rc == PCR_OK) rc = pcr_cloud_upload_f32(ctx, P.tgt, P.n_tgt, P.stride_tgt, &tgt);
+            if (rc == PCR_OK) rc = pcr_index_build(ctx, tgt, PCR_INDEX_GRID, 0.0, &index);
+            if (rc == PCR_OK) rc = pcr_icp(ctx, src, index, params, P.T0 ? P.T0 : eye, &results[i]);
+            if (status_out) status_out[i] = rc;
+            if (index) pcr_index_free(ctx, index);
+            if (tgt) pcr_cloud_free(ctx, tgt);
+            if (src) pcr_cloud_free(ctx, src);
+            if (rc < 0) {
+                int expected = PCR_OK;
+                hard_error.compare_exchange_strong(expected, rc);
+            }
+        }
+    };
+    if (n_ctx == 1) {
+        worker(ctxs[0]);
+    } else {
+        std::vector<std::thread> pool;
+        for (int c = 0; c < n_ctx; ++c) pool.emplace_back(worker, ctxs[c]);
+        for (auto& t : pool) t.join();
+    }
+    return hard_error.load();
 }
 
 int pcr_procrustes(const double* A, const double* B, int64_t k, double R_out[9], double t_out[3], double* cost_out) {

@@ -96,6 +96,8 @@ struct pcr_ctx {
     // pinned host scratch for the per-iteration moment read-back
     double* h_pinned = nullptr;
     void* h_state = nullptr;              // pinned 8-KiB staging buffer of the device-resident ICP state
+    void* h_stage = nullptr;              // pinned staging buffer for uploads from pageable caller memory (grown on demand, <= 64 MiB)
+    size_t h_stage_bytes = 0;
     size_t h_pinned_bytes = 0;
     int icp_lanes = 1;                    // runs of the source searched on separate streams per ICP pass (PCR_ICP_LANES)
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
