@@ -160,6 +160,28 @@ def test_register_batch_unequal_pairs_match_serial(pcp, syn):
         assert np.array_equal(a["T"], b["T"])
 
 
+def test_icp_batch_native_entry_point(pcp, oracle, syn):
+    """pcr_icp_batch (the pair loop of Registration/main.py:190-216 as one C call, native worker threads): results come back in
+    pair order whatever thread ran them, equal the reference semantics (compat goldens' oracle), an empty batch is a no-op and a
+    malformed pair raises instead of crashing."""
+    batch = __import__("importlib").import_module("point-cloud-process_amd.batch")
+    pairs = []
+    for i in range(9):
+        s6, t6, _ = syn.registration_pair_6f(3000 + 500 * (i % 3), seed=2000 + i)
+        pairs.append((s6, t6, None if i % 2 else np.eye(4)))
+    res = batch.native_register_share(pairs, device=0, streams=4)
+    assert len(res) == 9
+    for (s6, t6, _), r in zip(pairs, res):
+        ref = oracle.icp_point2point(s6[:, :3], t6[:, :3], np.eye(4))
+        assert r["iters"] == ref["iters"] and np.linalg.norm(r["T"] - ref["T"]) < 1e-9
+    assert batch.native_register_share([], device=0) == []
+    with pytest.raises(ValueError):
+        batch.native_register_share([(np.zeros((5, 2), np.float32), np.zeros((5, 3), np.float32), None)], device=0)
+    # an empty cloud inside a batch is a hard error of that pair (PCR_E_EMPTY), reported, not a crash
+    with pytest.raises(Exception):
+        batch.native_register_share([(np.zeros((0, 3), np.float32), pairs[0][1], None)], device=0)
+
+
 def test_dbscan_matches_reference_labels(pcp, oracle, syn):
     """Cluster_dbscan/dbscan.py: labels equal the reference's own output (goldens), numbering and noise quirks included."""
     g = load_golden("dbscan.npz")
