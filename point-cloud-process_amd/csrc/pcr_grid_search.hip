@@ -102,13 +102,18 @@ constexpr int WT_Q = PCR_WT_Q;      // queries per wave tile (16 or 32)
 #define PCR_WT_MAXC 384
 #endif
 constexpr int WT_MAXC = PCR_WT_MAXC;        // cells in a wave-tile box (a 7 x 7 x 7 box = 64 two-cell blocks fits: the gate ball of a sparse-region query at 0.8 m cells)
-constexpr int WT_PR = 192;          // points staged per round (3 chunks of 64, loaded back to back)
+#ifndef PCR_WT_PR
+#define PCR_WT_PR 192
+#endif
+constexpr int WT_PR = PCR_WT_PR;    // points staged per round (chunks of 64, loaded back to back)
+constexpr int WT_CH = WT_PR / 64;
+static_assert(WT_PR % 64 == 0, "whole chunks");
 #ifndef PCR_WT_PASSES
 #define PCR_WT_PASSES 3
 #endif
 constexpr int WT_PASSES = PCR_WT_PASSES;
 constexpr int WT_PASSES_SEEDED = WT_PASSES < 2 ? WT_PASSES : 2;
-constexpr int WT_ROUNDS_SMALL = 4, WT_ROUNDS_LARGE = 12;
+constexpr int WT_ROUNDS_SMALL = 768 / WT_PR, WT_ROUNDS_LARGE = 2304 / WT_PR;   // staged-point caps of 768 / 2304 per tile
 
 struct wtile_lds {
     alignas(16) float px[WT_PR + 8], py[WT_PR + 8], pz[WT_PR + 8];
@@ -414,19 +419,19 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
                 // owner cell of every staged position: mark the first position of each cell (slot ids increase with the
                 // position, cells are non-empty), then a running maximum over the positions
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) L->own[64 * c3 + lane] = 0;
+                for (int c3 = 0; c3 < WT_CH; ++c3) L->own[64 * c3 + lane] = 0;
                 wave_sync();
                 for (unsigned int c = lane; c < ncell; c += 64) {
                     const unsigned int f = L->c_off[c];
                     if (f >= base && f < base + cnt) L->own[f - base] = (unsigned short)c;
                 }
                 wave_sync();
-                unsigned int ow[3];
+                unsigned int ow[WT_CH];
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) ow[c3] = (unsigned int)L->own[64 * c3 + lane];
-                unsigned int jj[3];
+                for (int c3 = 0; c3 < WT_CH; ++c3) ow[c3] = (unsigned int)L->own[64 * c3 + lane];
+                unsigned int jj[WT_CH];
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) {
+                for (int c3 = 0; c3 < WT_CH; ++c3) {
                     unsigned int v = max(wave_incl_scan_max(ow[c3]), carry);
                     carry = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
                     const unsigned int k = 64 * c3 + lane;
@@ -434,12 +439,12 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
                     jj[c3] = L->c_start[vv] + (base + k - L->c_off[vv]);
                 }
                 // the (up to) three target records of this lane, requested back to back: one memory round trip per round
-                wt_xyz rec[3];
+                wt_xyz rec[WT_CH];
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3)
+                for (int c3 = 0; c3 < WT_CH; ++c3)
                     if (64 * c3 + lane < cnt) rec[c3] = *reinterpret_cast<const wt_xyz*>(&g_pts[jj[c3]]);
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) {
+                for (int c3 = 0; c3 < WT_CH; ++c3) {
                     const unsigned int k = 64 * c3 + lane;
                     if (k < cnt) {
                         L->px[k] = (float)(rec[c3].x - ox); L->py[k] = (float)(rec[c3].y - oy); L->pz[k] = (float)(rec[c3].z - oz);
