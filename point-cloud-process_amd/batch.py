@@ -10,6 +10,7 @@ never split.
 from __future__ import annotations
 
 import queue
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -66,6 +67,23 @@ def gpu_register_fn(device=0, nn="grid", mode="compat", streams=1, **icp_kw):
     return run
 
 
+_ctx_pool = {}
+_ctx_pool_lock = threading.Lock()
+_batch_lock = threading.Lock()
+
+
+def _pooled_contexts(device, n):
+    """n contexts on `device`, created once per process and reused by later batches: a context owns a stream, pinned staging
+    buffers and a 256-MiB device arena -- creating a dozen of them per call cost more than registering 100 pairs."""
+    from .device import Context
+
+    with _ctx_pool_lock:
+        have = _ctx_pool.setdefault(int(device), [])
+        while len(have) < n:
+            have.append(Context(device))
+        return have[:n]
+
+
 def native_register_share(pairs, device=0, streams=8, mode="compat", max_iter=100, r_thres=0.5, t_thres=0.5, max_d2=5.0,
                           r_metric="frobenius", min_iter=0, nn="grid"):
     """The local share of a batch through ONE C call (pcr_icp_batch): `streams` contexts on `device`, driven by native
@@ -74,15 +92,13 @@ def native_register_share(pairs, device=0, streams=8, mode="compat", max_iter=10
     import ctypes as C
 
     from . import _lib as L
-    from .device import Context
-
     if nn != "grid":
         raise ValueError("the native batch path uses the grid index")
     n = len(pairs)
     if n == 0:
         return []
-    ctxs = [Context(device) for _ in range(max(1, min(int(streams), n)))]
-    try:
+    ctxs = _pooled_contexts(device, max(1, min(int(streams), n)))
+    with _batch_lock:   # the pooled contexts are not thread-safe: one batch at a time per process
         arr = (L.Pair * n)()
         keep = []
         for i, (src, tgt, T0) in enumerate(pairs):
@@ -111,9 +127,6 @@ def native_register_share(pairs, device=0, streams=8, mode="compat", max_iter=10
         L.check(rc, ctxs[0].handle)
         return [{"T": np.array(r.T[:]).reshape(4, 4), "T_total": np.array(r.T_total[:]).reshape(4, 4), "iters": r.iters, "status": r.status,
                  "n_assoc": r.n_assoc, "cost": r.cost, "mean_d2": r.mean_d2} for r in res]
-    finally:
-        for c in ctxs:
-            c.close()
 
 
 def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, **kw):

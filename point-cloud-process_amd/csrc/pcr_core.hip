@@ -339,6 +339,26 @@ static int upload_impl(pcr_ctx* ctx, const S* xyz, int64_t n, int64_t stride, pc
             h_src = ctx->h_stage;
         }
     }
+    // small clouds (the batched registration's 20 000-point scans): their exact bounding box is taken on the host while the
+    // data is in cache anyway -- it saves the device reduction and its read-back synchronisation in the index build and in the
+    // Morton lay-out.  (S -> double is exact; NaNs fail every comparison and poison nothing, the device path rejects them)
+    if (n <= 65536) {
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool finite = true;
+        for (int64_t i = 0; i < n; ++i) {
+            const S* p = xyz + i * stride;
+            for (int k = 0; k < 3; ++k) {
+                const double v = (double)p[k];
+                finite = finite && std::isfinite(v);
+                lo[k] = v < lo[k] ? v : lo[k];
+                hi[k] = v > hi[k] ? v : hi[k];
+            }
+        }
+        if (finite) {
+            c->has_bbox = true;
+            for (int k = 0; k < 3; ++k) { c->lo[k] = lo[k]; c->hi[k] = hi[k]; }
+        }
+    }
     PCR_HIP(ctx, hipMemcpyAsync(d_raw, h_src, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
     int block = 256;
     int grid = (int)((n + block - 1) / block);
@@ -408,6 +428,7 @@ int pcr_cloud_transform(pcr_ctx* ctx, pcr_cloud* c, const double T[16]) {
     pcr_xform_from_T(T, &x);
     int block = 256;
     int grid = (int)((c->n + block - 1) / block);
+    c->has_bbox = false;
     hipLaunchKernelGGL(transform_cloud_kernel, dim3(grid), dim3(block), 0, ctx->stream, c->d, (long long)c->n, x);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;

@@ -46,6 +46,8 @@ __global__ void bbox_partial_kernel(const pcr_pt* __restrict__ pts, long long n,
     if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
+__global__ void store_view_kernel(pcr_grid_view v, pcr_grid_view* __restrict__ out) { *out = v; }
+
 __global__ void morton_keys_kernel(const pcr_pt* __restrict__ pts, long long n, double lox, double loy, double loz,
                                    double inv, unsigned long long* __restrict__ keys, unsigned int* __restrict__ vals) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,6 +193,26 @@ int pcr_bbox(pcr_ctx* ctx, const pcr_pt* pts, long long n, double lo[3], double 
     return PCR_OK;
 }
 
+// Morton keys of a cloud whose coordinates span `ext` metres from its min corner: every cell coordinate is BIAS + k with
+// 0 <= k <= ext / cell, so only the low 3 * bits(k_max) key bits differ between points (the bias bit and the zeros below it
+// are the same for all): the radix sort only needs those (30 of 63 bits on a KITTI scan: half the passes).
+static int morton_end_bit(const double lo[3], const double hi[3], double inv) {
+    double kmax = 0.0;
+    for (int k = 0; k < 3; ++k) kmax = fmax(kmax, floor((hi[k] - lo[k]) * inv) + 2.0);   // +1 rounding slack, +1 for "count"
+    int nb = 1;
+    while (nb < PCR_COORD_BITS - 1 && (double)(1ll << nb) <= kmax) ++nb;
+    const int end = 3 * nb;
+    return end > 63 ? 63 : end;
+}
+
+int pcr_cloud_bbox(pcr_ctx* ctx, const pcr_cloud* c, double lo[3], double hi[3]) {
+    if (c->has_bbox) {
+        for (int k = 0; k < 3; ++k) { lo[k] = c->lo[k]; hi[k] = c->hi[k]; }
+        return PCR_OK;
+    }
+    return pcr_bbox(ctx, c->d, c->n, lo, hi);
+}
+
 // idx->lo/hi must already hold the target's bounding box (pcr_index_build computes it).
 int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* idx) {
     const long long n = tgt->n;
@@ -230,10 +252,11 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
     hipLaunchKernelGGL(morton_keys_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)tgt->d, n, lo[0], lo[1], lo[2],
                        inv, d_keys, d_vals);
     size_t temp_bytes = 0;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, 63, ctx->stream));
+    const int end_bit = morton_end_bit(lo, hi, inv);
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
     void* d_temp = nullptr;
     if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, 63, ctx->stream));
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
     if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&idx->sorted))) return rc;
     hipLaunchKernelGGL(gather_sorted_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)tgt->d,
                        (const unsigned int*)d_vals2, n, idx->sorted);
@@ -301,9 +324,10 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
     }
     // device copy of the view: the search kernels read it through a pointer (scalar loads of the few fields a wave
     // needs) instead of carrying its 400 bytes in kernel-argument SGPRs
+    // (written by a one-thread kernel that takes the view as its argument: no host copy, no synchronisation)
     if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_grid_view), (void**)&idx->d_view))) return rc;
-    PCR_HIP(ctx, hipMemcpyAsync(idx->d_view, &idx->view, sizeof(pcr_grid_view), hipMemcpyHostToDevice, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // idx->view is pageable host memory
+    hipLaunchKernelGGL(store_view_kernel, dim3(1), dim3(1), 0, ctx->stream, idx->view, idx->d_view);
+    PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
 
@@ -313,7 +337,7 @@ int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell) {
     const int block = 256;
     const int grid_n = (int)((n + block - 1) / block);
     double lo[3], hi[3];
-    int rc = pcr_bbox(ctx, c->d, n, lo, hi);
+    int rc = pcr_cloud_bbox(ctx, c, lo, hi);
     if (rc) return rc;
     const double emax = fmax(hi[0] - lo[0], fmax(hi[1] - lo[1], hi[2] - lo[2]));
     if (!(cell > 0)) cell = emax > 0 ? emax / 1024.0 : 1.0;
@@ -329,10 +353,11 @@ int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell) {
     hipLaunchKernelGGL(morton_keys_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, n, lo[0], lo[1], lo[2],
                        1.0 / cell, d_keys, d_vals);
     size_t temp_bytes = 0;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, 63, ctx->stream));
+    const int end_bit = morton_end_bit(lo, hi, 1.0 / cell);
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
     void* d_temp = nullptr;
     if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, 63, ctx->stream));
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
     hipLaunchKernelGGL(gather_sorted_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, (const unsigned int*)d_vals2, n,
                        d_out);
     PCR_HIP(ctx, hipGetLastError());

@@ -24,7 +24,7 @@ int pcr_index_build(pcr_ctx* ctx, const pcr_cloud* target, int kind, double cell
     idx->kind = kind;
     idx->n = target->n;
     memset(&idx->view, 0, sizeof(idx->view));
-    int rc = pcr_bbox(ctx, target->d, target->n, idx->lo, idx->hi);
+    int rc = pcr_cloud_bbox(ctx, target, idx->lo, idx->hi);
     if (rc == PCR_OK) {
         for (int k = 0; k < 3; ++k) idx->view.origin[k] = 0.5 * (idx->lo[k] + idx->hi[k]);
         rc = (kind == PCR_INDEX_GRID) ? pcr_grid_build(ctx, target, cell, idx) : pcr_brute_build(ctx, target, idx);
@@ -125,6 +125,13 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
     if (source->n <= 0) return PCR_E_EMPTY;
     hipSetDevice(ctx->device);
     memset(res, 0, sizeof(*res));
+    // the passes transform the source in place: lay it out first (the Morton sort may still use the box remembered from the
+    // upload), then forget that box
+    if (index->kind == PCR_INDEX_GRID) {
+        const int rs = pcr_cloud_morton_sort(ctx, source, index->cell);
+        if (rs) return rs;
+    }
+    source->has_bbox = false;
     const bool compat = params->mode == PCR_ICP_COMPAT_MAIN;
     PCR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     int rc = PCR_OK;

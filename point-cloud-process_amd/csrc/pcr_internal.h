@@ -60,6 +60,8 @@ struct pcr_cloud {
     pcr_pt* d = nullptr;
     int64_t n = 0;
     bool morton_sorted = false;  // records reordered for spatial locality (id keeps the caller's row)
+    bool has_bbox = false;       // lo/hi below are the exact bounding box of the records (computed on the host while uploading;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // dropped as soon as the cloud is transformed)
 };
 
 struct pcr_index {
@@ -146,6 +148,8 @@ PCR_HIDDEN void pcr_prof_finish(pcr_ctx* ctx);
 
 // grid (pcr_grid.hip)
 PCR_HIDDEN int pcr_bbox(pcr_ctx* ctx, const pcr_pt* pts, long long n, double lo[3], double hi[3]);
+// bounding box of a cloud: the one remembered from the upload if still valid, otherwise a device reduction + read-back
+PCR_HIDDEN int pcr_cloud_bbox(pcr_ctx* ctx, const pcr_cloud* c, double lo[3], double hi[3]);
 PCR_HIDDEN int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* idx);
 // Reorder a cloud's records along a Morton curve (cell = curve resolution); rigid transforms keep the locality.
 PCR_HIDDEN int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell);

@@ -1,0 +1,13 @@
+"""64 registration_dataset-shaped pairs (20 000 points) through pcr_icp_batch: driver for rocprofv3 kernel stats."""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pcp = importlib.import_module("point-cloud-process_amd")
+batch = importlib.import_module("point-cloud-process_amd.batch")
+pairs = [(s, t, None) for s, t, _ in pcp.synthetic.registration_batch_6f(64, 20000, seed=1000)]
+streams = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+batch.native_register_share(pairs[:4], device=0, streams=2)
+t0 = time.perf_counter()
+res = batch.native_register_share(pairs, device=0, streams=streams)
+el = time.perf_counter() - t0
+print("pairs/s %.0f  mean iters %.2f" % (len(pairs) / el, np.mean([r["iters"] for r in res])))
