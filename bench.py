@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--no-brute", action="store_true", help="skip the brute-force MFMA leg")
     ap.add_argument("--in-flight", type=int, default=4, help="pairs in flight for the supplementary concurrent leg (0 = skip)")
     ap.add_argument("--no-batch", action="store_true", help="skip the batch256 block (BASELINE configs[3])")
-    ap.add_argument("--batch-streams", type=int, default=12, help="pairs in flight per GPU in the batch256 block (4 / 8 / 12 measured 4.1 / 4.8 / 5.1 k pairs/s)")
+    ap.add_argument("--batch-streams", type=int, default=8, help="pairs in flight per GPU in the batch256 block (contexts = native worker threads)")
     a = ap.parse_args()
 
     if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:

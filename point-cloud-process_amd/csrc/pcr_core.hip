@@ -65,6 +65,15 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
         hipMalloc((void**)&c->d_debug, sizeof(unsigned long long) << 20);
         hipMemsetAsync(c->d_debug, 0, sizeof(unsigned long long) << 20, c->stream);
     }
+    // first arena now, not inside the first upload: a 256-MiB hipMalloc takes milliseconds under the driver's lock, and a
+    // dozen fresh contexts paying it inside a timed batch cost more than the batch's kernels
+    {
+        void* warm = nullptr;
+        if (pcr_dev_alloc(c, 256, &warm) == PCR_OK) pcr_dev_free(c, warm, 256);
+        // same for the pinned upload staging buffer (hipHostMalloc pins pages under a lock: ~2 ms)
+        if (hipHostMalloc(&c->h_stage, 4u << 20, hipHostMallocMapped) == hipSuccess) c->h_stage_bytes = 4u << 20;
+        else c->h_stage = nullptr;
+    }
     *out = c;
     return PCR_OK;
 }
@@ -317,27 +326,33 @@ static int upload_impl(pcr_ctx* ctx, const S* xyz, int64_t n, int64_t stride, pc
     int rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&c->d);
     if (rc != PCR_OK) { delete c; return rc; }
     size_t raw_elems = (size_t)(n - 1) * stride + 3;
-    void* d_raw = nullptr;
-    rc = pcr_dev_alloc(ctx, raw_elems * sizeof(S), &d_raw);
-    if (rc != PCR_OK) { pcr_dev_free(ctx, c->d, sizeof(pcr_pt) * n); delete c; return rc; }
-    // Caller buffers are pageable: the runtime stages such copies through its own pinned buffers under a lock (~4.5 GB/s
-    // in aggregate, however many contexts copy at once -- the batch of BASELINE config 4 was bound by exactly that).  Copy into
-    // this context's own pinned buffer first (a plain memcpy in the calling thread) and DMA from there.
+    // Caller buffers are pageable: the runtime stages such copies through its own pinned buffers under a lock (~4.5 GB/s in
+    // aggregate, however many contexts copy at once), and even copies from pinned memory are submitted through one queue per
+    // device (12 contexts uploading at once each waited 12x as long).  So: a plain memcpy into this context's own pinned,
+    // device-mapped buffer, and the expand kernel reads the 12 useful bytes of every record straight from there over PCIe.
     const size_t raw_bytes = raw_elems * sizeof(S);
-    const void* h_src = xyz;
+    const S* d_src = nullptr;     // what the expand kernel reads
+    void* d_raw = nullptr;
     if (raw_bytes <= (64u << 20)) {
         if (ctx->h_stage_bytes < raw_bytes) {
             if (ctx->h_stage) hipHostFree(ctx->h_stage);
             ctx->h_stage = nullptr;
             ctx->h_stage_bytes = 0;
             size_t want = raw_bytes < (4u << 20) ? (4u << 20) : raw_bytes;
-            if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) == hipSuccess) ctx->h_stage_bytes = want;
+            if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocMapped) == hipSuccess) ctx->h_stage_bytes = want;
             else ctx->h_stage = nullptr;
         }
         if (ctx->h_stage) {
             memcpy(ctx->h_stage, xyz, raw_bytes);
-            h_src = ctx->h_stage;
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, ctx->h_stage, 0) == hipSuccess) d_src = (const S*)dp;
         }
+    }
+    if (!d_src) {   // very large clouds (or no pinned memory): device staging buffer + the runtime's own copy
+        rc = pcr_dev_alloc(ctx, raw_bytes, &d_raw);
+        if (rc != PCR_OK) { pcr_dev_free(ctx, c->d, sizeof(pcr_pt) * n); delete c; return rc; }
+        PCR_HIP(ctx, hipMemcpyAsync(d_raw, xyz, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_src = (const S*)d_raw;
     }
     // small clouds (the batched registration's 20 000-point scans): their exact bounding box is taken on the host while the
     // data is in cache anyway -- it saves the device reduction and its read-back synchronisation in the index build and in the
@@ -359,15 +374,13 @@ static int upload_impl(pcr_ctx* ctx, const S* xyz, int64_t n, int64_t stride, pc
             for (int k = 0; k < 3; ++k) { c->lo[k] = lo[k]; c->hi[k] = hi[k]; }
         }
     }
-    PCR_HIP(ctx, hipMemcpyAsync(d_raw, h_src, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
     int block = 256;
     int grid = (int)((n + block - 1) / block);
-    hipLaunchKernelGGL(expand_cloud_kernel<S>, dim3(grid), dim3(block), 0, ctx->stream, (const S*)d_raw, (long long)n,
-                       (long long)stride, c->d);
+    hipLaunchKernelGGL(expand_cloud_kernel<S>, dim3(grid), dim3(block), 0, ctx->stream, d_src, (long long)n, (long long)stride, c->d);
     PCR_HIP(ctx, hipGetLastError());
-    // the host buffer is caller-owned: finish reading it before returning
+    // the staging buffer is reused by the next upload (and an unstaged copy reads caller-owned memory): finish before returning
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pcr_dev_free(ctx, d_raw, raw_elems * sizeof(S));
+    if (d_raw) pcr_dev_free(ctx, d_raw, raw_bytes);
     *out = c;
     return PCR_OK;
 }

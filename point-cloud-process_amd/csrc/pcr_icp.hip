@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include "pcr_internal.h"
@@ -208,7 +209,10 @@ int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_
         if (!ctxs[c]) return PCR_E_INVALID;
     std::atomic<int64_t> next(0);
     std::atomic<int> hard_error(PCR_OK);
+    static const bool timing = getenv("PCR_BATCH_TIMING") != nullptr;   // diagnostics: mean microseconds per phase and pair
+    std::atomic<long long> t_ns[4] = {{0}, {0}, {0}, {0}};
     static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const auto wall0 = std::chrono::steady_clock::now();
     auto worker = [&](pcr_ctx* ctx) {
         hipSetDevice(ctx->device);
         for (;;) {
@@ -217,10 +221,20 @@ int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_
             const pcr_pair& P = pairs[i];
             pcr_cloud *src = nullptr, *tgt = nullptr;
             pcr_index* index = nullptr;
+            auto now = [] { return std::chrono::steady_clock::now(); };
+            auto t0 = now();
             int rc = pcr_cloud_upload_f32(ctx, P.src, P.n_src, P.stride_src, &src);
             if (rc == PCR_OK) rc = pcr_cloud_upload_f32(ctx, P.tgt, P.n_tgt, P.stride_tgt, &tgt);
+            auto t1 = now();
             if (rc == PCR_OK) rc = pcr_index_build(ctx, tgt, PCR_INDEX_GRID, 0.0, &index);
+            auto t2 = now();
             if (rc == PCR_OK) rc = pcr_icp(ctx, src, index, params, P.T0 ? P.T0 : eye, &results[i]);
+            auto t3 = now();
+            if (timing) {
+                t_ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+                t_ns[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+                t_ns[2] += std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count();
+            }
             if (status_out) status_out[i] = rc;
             if (index) pcr_index_free(ctx, index);
             if (tgt) pcr_cloud_free(ctx, tgt);
@@ -238,6 +252,10 @@ int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_
         for (int c = 0; c < n_ctx; ++c) pool.emplace_back(worker, ctxs[c]);
         for (auto& t : pool) t.join();
     }
+    if (timing && n_pairs > 0)
+        fprintf(stderr, "pcr_icp_batch: %lld pairs on %d contexts in %.2f ms; per pair: uploads %.0f us, index build %.0f us, icp %.0f us\n", (long long)n_pairs,
+                n_ctx, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - wall0).count() / 1e3,
+                t_ns[0] / 1e3 / n_pairs, t_ns[1] / 1e3 / n_pairs, t_ns[2] / 1e3 / n_pairs);
     return hard_error.load();
 }
 
