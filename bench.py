@@ -351,7 +351,7 @@ def main():
         ctx.profile(False)
         kern = {}
         if a.nn == "grid":
-            names = ["grid_wtile_kernel", "grid_hard_kernel", "-", "-"]   # the hard-stage launch also accumulates, solves and tests (fused)
+            names = ["grid_pass_kernel", "-", "-", "-"]   # ONE launch per iteration: tiles, hard queue, moments, Procrustes, convergence test
         else:
             names = ["brute_nn_kernel", "brute_merge_kernel+brute_exact_kernel", "brute_final_kernel", "brute_reduce_partials_kernel"]
         for nm, ms in zip(names, prof_ms):
@@ -399,12 +399,12 @@ def main():
             "n_assoc_last": int(r["n_assoc"]),
             "roofline": roofline,
         }
-        if a.nn == "grid" and "grid_wtile_kernel" in kern:
+        if a.nn == "grid" and "grid_pass_kernel" in kern:
             try:
                 fpairs, mean_p = filter_pairs_per_pass(pkg, dev_id, src, tgt, a.cell)
-                tile_s = kern["grid_wtile_kernel"] * 1e-6
+                tile_s = kern["grid_pass_kernel"] * 1e-6
                 ach = fpairs * FILTER_LANE_OPS_PER_PAIR / tile_s
-                line["roofline_valu"] = {"bound": "valu", "kernel": "grid_wtile_kernel", "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
+                line["roofline_valu"] = {"bound": "valu", "kernel": "grid_pass_kernel", "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
                                          "unit": "Tlane-op/s (f32)", "frac": ach / VALU_PEAK_LANE_OPS,
                                          "filter_pairs_per_launch": fpairs, "mean_candidates_per_query": mean_p,
                                          "lane_ops_per_pair": FILTER_LANE_OPS_PER_PAIR,

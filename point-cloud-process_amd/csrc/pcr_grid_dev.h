@@ -66,32 +66,50 @@ __device__ static inline unsigned long long cell_pack(unsigned int x, unsigned i
 // The table is made of 64-byte buckets of 4 slots, filled from slot 0 (load factor <= 0.25): a
 // lookup is one cache line in almost every case, and an empty slot in the bucket proves absence.
 // `mask` = number of buckets - 1.
+// The bucket is fetched as four 16-byte GLOBAL loads issued together and pinned before the first compare: written
+// field by field through the generic pointer of the grid view, the compiler fetched the keys first and the (start, end)
+// of the matching slot in a second, dependent round trip (flat loads, each followed by a full wait).
+typedef unsigned int pcr_u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) pcr_u4* pcr_gu4p;
+__device__ static inline unsigned long long u4_key(const pcr_u4& v) { return (unsigned long long)v.x | ((unsigned long long)v.y << 32); }
+
 __device__ static inline bool lookup_cell(const pcr_cell_slot* __restrict__ tab, unsigned int mask, unsigned int x, unsigned int y,
                                           unsigned int z, unsigned int* s, unsigned int* e) {
+    static_assert(sizeof(pcr_cell_slot) == 16, "one slot = one 16-byte load");
     const unsigned long long key = cell_pack(x, y, z);
     unsigned int b = cell_hash(x, y, z) & mask;
+    const pcr_gu4p base = (pcr_gu4p)(const void*)tab;
     for (unsigned int probe = 0; probe <= mask; ++probe) {
-        const pcr_cell_slot* __restrict__ bk = tab + (size_t)b * 4;
-        const pcr_cell_slot s0 = bk[0], s1 = bk[1], s2 = bk[2], s3 = bk[3];
-        if (s0.key == key) { *s = s0.start; *e = s0.end; return true; }
-        if (s1.key == key) { *s = s1.start; *e = s1.end; return true; }
-        if (s2.key == key) { *s = s2.start; *e = s2.end; return true; }
-        if (s3.key == key) { *s = s3.start; *e = s3.end; return true; }
-        if (s3.key == PCR_EMPTY_KEY) return false;  // buckets fill from slot 0: a free last slot means the bucket never overflowed
+        const pcr_gu4p bk = base + (size_t)b * 4;
+        pcr_u4 s0 = bk[0], s1 = bk[1], s2 = bk[2], s3 = bk[3];
+        asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));   // all four here, now
+        if (u4_key(s0) == key) { *s = s0.z; *e = s0.w; return true; }
+        if (u4_key(s1) == key) { *s = s1.z; *e = s1.w; return true; }
+        if (u4_key(s2) == key) { *s = s2.z; *e = s2.w; return true; }
+        if (u4_key(s3) == key) { *s = s3.z; *e = s3.w; return true; }
+        if (u4_key(s3) == PCR_EMPTY_KEY) return false;  // buckets fill from slot 0: a free last slot means the bucket never overflowed
         b = (b + 1) & mask;
     }
     return false;
 }
 
-// 2x2x2-block lookup: one 32-byte read in almost every case
+// 2x2x2-block lookup: one 32-byte read in almost every case (both halves requested together, see lookup_cell)
 __device__ static inline bool lookup_block(const pcr_block_slot* __restrict__ tab, unsigned int mask, unsigned int bx, unsigned int by,
                                            unsigned int bz, pcr_block_slot* out) {
+    static_assert(sizeof(pcr_block_slot) == 32, "one slot = two 16-byte loads");
     const unsigned long long key = cell_pack(bx, by, bz);
     unsigned int b = cell_hash(bx, by, bz) & mask;
+    const pcr_gu4p base = (pcr_gu4p)(const void*)tab;
     for (unsigned int probe = 0; probe <= mask; ++probe) {
-        const pcr_block_slot e = tab[b];
-        if (e.key == key) { *out = e; return true; }
-        if (e.key == PCR_EMPTY_KEY) return false;
+        pcr_u4 lo = base[(size_t)b * 2], hi = base[(size_t)b * 2 + 1];
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        const unsigned long long k = u4_key(lo);
+        if (k == key) {
+            pcr_u4 w[2] = {lo, hi};
+            __builtin_memcpy(out, w, 32);
+            return true;
+        }
+        if (k == PCR_EMPTY_KEY) return false;
         b = (b + 1) & mask;
     }
     return false;

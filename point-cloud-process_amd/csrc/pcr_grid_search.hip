@@ -112,7 +112,10 @@ static_assert(WT_PR % 64 == 0, "whole chunks");
 #define PCR_WT_PASSES 3
 #endif
 constexpr int WT_PASSES = PCR_WT_PASSES;
-constexpr int WT_PASSES_SEEDED = WT_PASSES < 2 ? WT_PASSES : 2;
+#ifndef PCR_WT_PASSES_SEEDED
+#define PCR_WT_PASSES_SEEDED 1
+#endif
+constexpr int WT_PASSES_SEEDED = WT_PASSES < PCR_WT_PASSES_SEEDED ? WT_PASSES : PCR_WT_PASSES_SEEDED;
 constexpr int WT_ROUNDS_SMALL = 768 / WT_PR, WT_ROUNDS_LARGE = 2304 / WT_PR;   // staged-point caps of 768 / 2304 per tile
 
 struct wtile_lds {
@@ -202,25 +205,56 @@ __device__ static inline const T* as_global(const T* p) {
     return (const T*)(const __attribute__((address_space(1))) T*)p;
 }
 
+// what a wave tile leaves behind in every lane (the 64 / WT_Q copies of a query agree)
+struct wt_state {
+    double ax, ay, az;        // the transformed query
+    long long qi;
+    float bound2;             // squared radius that provably holds the nearest neighbour (or the gate)
+    unsigned int cand_pos;    // the candidate behind bound2 (POS_NONE: only the gate, or nothing, bounds the search)
+    unsigned int won;         // proven nearest neighbour; POS_NONE = nothing within the gate, or still open
+    bool open, clamped, qvalid;
+    unsigned long long dbg_pairs;
+    unsigned int dbg_passes;
+};
+
+// what a tile needs from memory before anything else: requested in one go by the caller (with whatever else it needs then)
+struct wt_pre {
+    pcr_pt p;                 // the query record
+    unsigned int seed_pos;    // ICP passes after the first: the previous pass's neighbour (res_pos) ...
+    wt_xyz seed_b;            // ... and its coordinates (prev_xyz); stale where seed_pos is POS_NONE
+};
+__device__ __forceinline__ static void wtile_preload(const unsigned int tile, const int lane, const pcr_pt* __restrict__ q, const long long nq,
+                                                     const unsigned int* __restrict__ res_pos, const wt_xyz* __restrict__ prev_xyz, wt_pre& P) {
+    const long long qi = (long long)tile * WT_Q + (lane & (WT_Q - 1));
+    P.seed_pos = POS_NONE;
+    P.seed_b = wt_xyz{0.0, 0.0, 0.0};
+    P.p.x = P.p.y = P.p.z = 0.0; P.p.id = 0;
+    if (qi < nq) {
+        // the seed travels with the query record: three dependent round trips (record -> res_pos -> prev_xyz) measured 2.7 us
+        // at the head of every tile
+        if (prev_xyz) {
+            P.seed_pos = res_pos[qi];
+            P.seed_b = prev_xyz[qi];
+        }
+        P.p = q[qi];
+    }
+}
+
 #ifndef PCR_WT_WAVES
 #define PCR_WT_WAVES 4   // keep the register allocator at <= 128 VGPRs: it drifts to 130-145 (3 waves per SIMD) on small edits
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
-grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
-                  int gated, int xcd_remap, unsigned int pcap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2,
-                  work_item* __restrict__ hard_list, unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg,
-                  const pcr_icp_dev_state* __restrict__ st, const wt_xyz* __restrict__ prev_xyz, unsigned int* __restrict__ open_mask) {
+// The tile search proper, shared by the stand-alone tile kernel (nn1 API, host loop) and the one-kernel ICP pass.
+// `tile` = index of the wave's run of WT_Q queries; proven queries have their res_pos (res_d2) written here.
+__device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wtile_lds* L, const unsigned int tile, const int lane, const wt_pre& P,
+                                                    pcr_pt* __restrict__ q, const long long nq, const pcr_xform& x, const int has_x, const int write_back,
+                                                    const double max_d2, const int gated, const unsigned int pcap, unsigned int* __restrict__ res_pos,
+                                                    double* __restrict__ res_d2, unsigned long long* __restrict__ dbg,
+                                                    const wt_xyz* __restrict__ prev_xyz, wt_state& S) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ wtile_lds s_lds[4];
-    if (st) {
-        if (st->stop) return;
-        x = st->x;
-    }
-    const pcr_grid_view& gv = *gvp;  // uniform address: fields arrive by scalar loads when they are needed
     const pcr_pt* __restrict__ g_pts = as_global(gv.pts);
-    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
 #ifdef PCR_WT_DIAG   // phase stamps + "why still open" counters for scripts/wt_stamps.py: a diagnostic build only (they cost registers)
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = t_start;
 #define WT_STAMP(i) do { if (dbg) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_ph[i] += t_now - t_last; t_last = t_now; } } while (0)
 #define WT_WHY(v) do { why = (v); } while (0)
@@ -229,19 +263,14 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
 #define WT_STAMP(i) do {} while (0)
 #define WT_WHY(v) do {} while (0)
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    wtile_lds* L = &s_lds[wave];
-    unsigned int blk = blockIdx.x;
-    if (xcd_remap) {  // every XCD (own L2) gets one contiguous run of the Morton-sorted queries
-        const unsigned int per = gridDim.x >> 3, main = per << 3;
-        if (blk < main) blk = (blk & 7u) * per + (blk >> 3);
-    }
-    const long long qi = ((long long)blk * 4 + wave) * WT_Q + (lane & (WT_Q - 1));
+    const long long qi = (long long)tile * WT_Q + (lane & (WT_Q - 1));
     const bool qvalid = qi < nq;
     double ax = 0, ay = 0, az = 0;
     bool clamped = false;
+    const unsigned int seed_pos = P.seed_pos;
+    const wt_xyz seed_b = P.seed_b;
     if (qvalid) {
-        const pcr_pt p = q[qi];
+        const pcr_pt p = P.p;
         ax = p.x; ay = p.y; az = p.z;
         if (has_x) {
             xform_apply(x, p, &ax, &ay, &az);
@@ -263,16 +292,16 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
     bool open = qvalid;                         // not yet proven
     const float gate2 = gated ? (float)max_d2 * (1.0f + 1e-6f) : INFINITY;   // rounded up: only ever used as an outer bound
     float bound2 = gate2;                       // squared radius that provably holds the nearest neighbour (or the gate)
-    unsigned int cand_pos = POS_NONE;
+    unsigned int cand_pos = POS_NONE, won = POS_NONE;
     if (prev_xyz && qvalid && !clamped) {
         // ICP iterations after the first: res_pos still holds every query's neighbour of the PREVIOUS pass (the target
         // never changes) and prev_xyz its coordinates (the accumulate kernel, which gathers the record anyway, leaves them
         // there: no dependent gather here).  The exact distance from the query's new position to that point bounds the
         // search ball at once, so the first box is the bounding box of tight balls instead of cells + 1 ring, and one
         // pass proves almost every query.
-        const unsigned int pp = res_pos[qi];
+        const unsigned int pp = seed_pos;
         if (pp != POS_NONE) {
-            const wt_xyz b = prev_xyz[qi];
+            const wt_xyz b = seed_b;
             const double dx = ax - b.x, dy = ay - b.y, dz = az - b.z;
             const float up = (float)((dx * dx + dy * dy) + dz * dz) * (1.0f + 2e-7f) + 1e-37f;   // rounded up
             if (up < bound2) { bound2 = up; cand_pos = pp; }
@@ -532,6 +561,7 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
             if (!ambiguous && reach2 <= db * db * (1.0f - 2e-6f)) {
                 // proven: the filter's winner is the exact nearest neighbour, or nothing lies within the gate
                 open = false;
+                won = bpos;
                 if (lane < WT_Q) {
                     if (res_d2) {
                         double dd = DBL_MAX;
@@ -541,7 +571,7 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
                         }
                         res_d2[qi] = dd;
                     }
-                    res_pos[qi] = bpos;
+                    if (bpos != seed_pos) res_pos[qi] = bpos;   // (seeded passes: most neighbours do not change)
                 }
             } else {
                 WT_WHY(ambiguous ? 3 : 4);
@@ -553,10 +583,56 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
         }
     }
     WT_STAMP(6);
+    S.ax = ax; S.ay = ay; S.az = az;
+    S.qi = qi;
+    S.bound2 = bound2;
+    S.cand_pos = cand_pos;
+    S.won = won;
+    S.open = open; S.clamped = clamped; S.qvalid = qvalid;
+    S.dbg_pairs = dbg_pairs; S.dbg_passes = dbg_passes;
+#ifdef PCR_WT_DIAG
+    if (dbg) {
+        const bool unres = open && lane < WT_Q;
+        for (int r = 0; r < 5; ++r) {
+            const unsigned int n_r = (unsigned int)__popcll(__ballot(unres && (clamped ? 0 : why) == r));
+            if (lane == 0 && n_r) atomicAdd(&dbg[(1 << 15) + r], (unsigned long long)n_r);
+        }
+        if (lane == 0 && (threadIdx.x >> 6) == 0)
+            for (int i = 0; i < 8; ++i) dbg[(1 << 16) + blockIdx.x * 8 + i] = t_ph[i];
+    }
+#endif
+}
+
+// tile index of a wave: every XCD (own L2) gets one contiguous run of the Morton-sorted queries
+__device__ static inline unsigned int wtile_block(int xcd_remap) {
+    unsigned int blk = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = gridDim.x >> 3, main = per << 3;
+        if (blk < main) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    return blk;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
+grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q, long long nq, pcr_xform x, int has_x, int write_back, double max_d2,
+                  int gated, int xcd_remap, unsigned int pcap, unsigned int* __restrict__ res_pos, double* __restrict__ res_d2,
+                  work_item* __restrict__ hard_list, unsigned int* __restrict__ hard_count, unsigned long long* __restrict__ dbg,
+                  const pcr_icp_dev_state* __restrict__ st, const wt_xyz* __restrict__ prev_xyz) {
+    __shared__ wtile_lds s_lds[4];
+    if (st) {
+        if (st->stop) return;
+        x = st->x;
+    }
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int blk = wtile_block(xcd_remap);
+    wt_state S;
+    wt_pre P;
+    wtile_preload(blk * 4 + wave, lane, q, nq, res_pos, prev_xyz, P);
+    wtile_search(*gvp, &s_lds[wave], blk * 4 + wave, lane, P, q, nq, x, has_x, write_back, max_d2, gated, pcap, res_pos, res_d2, dbg, prev_xyz, S);
     // ---- what is still open goes to the hard stage: one append per wave
-    const bool unres = open && lane < WT_Q;
+    const bool unres = S.open && lane < WT_Q;
     const unsigned long long m = __ballot(unres);
-    if (open_mask && lane == 0) open_mask[(size_t)blk * 4 + wave] = (unsigned int)m;   // which of the tile's queries the hard stage owns
     if (m) {
         const unsigned int n_unres = __popcll(m);
         unsigned int base = 0;
@@ -565,32 +641,18 @@ grid_wtile_kernel(const pcr_grid_view* __restrict__ gvp, pcr_pt* __restrict__ q,
         base = __shfl(base, 0, 64);
         if (unres) {
             work_item it;
-            it.ax = ax; it.ay = ay; it.az = az;
-            it.best_d2 = (clamped || cand_pos == POS_NONE) ? DBL_MAX : (double)bound2;
-            it.best_pos = clamped ? POS_NONE : cand_pos;
-            it.qi = (unsigned int)qi;
+            it.ax = S.ax; it.ay = S.ay; it.az = S.az;
+            it.best_d2 = (S.clamped || S.cand_pos == POS_NONE) ? DBL_MAX : (double)S.bound2;
+            it.best_pos = S.clamped ? POS_NONE : S.cand_pos;
+            it.qi = (unsigned int)S.qi;
             hard_list[base + __popcll(m & ((1ull << lane) - 1ull))] = it;
         }
     }
-#ifdef PCR_WT_DIAG
-    unsigned int dbg_why[5] = {0, 0, 0, 0, 0};
-    if (dbg)
-        for (int r = 0; r < 5; ++r) dbg_why[r] = (unsigned int)__popcll(__ballot(unres && (clamped ? 0 : why) == r));
-#endif
     if (dbg && lane == 0) {
-        atomicAdd(&dbg[blockIdx.x * 4 + 1], dbg_pairs);
-        atomicAdd(&dbg[blockIdx.x * 4 + 2], (unsigned long long)dbg_passes);
+        atomicAdd(&dbg[blockIdx.x * 4 + 1], S.dbg_pairs);
+        atomicAdd(&dbg[blockIdx.x * 4 + 2], (unsigned long long)S.dbg_passes);
         atomicAdd(&dbg[blockIdx.x * 4 + 3], (unsigned long long)__popcll(m));
-#ifdef PCR_WT_DIAG
-        for (int r = 0; r < 5; ++r)
-            if (dbg_why[r]) atomicAdd(&dbg[(1 << 15) + r], (unsigned long long)dbg_why[r]);
-#endif
         atomicMax(&dbg[blockIdx.x * 4 + 0], __builtin_amdgcn_s_memtime() - t_start);
-#ifdef PCR_WT_DIAG
-        WT_STAMP(7);
-        if (wave == 0)
-            for (int i = 0; i < 8; ++i) dbg[(1 << 16) + blockIdx.x * 8 + i] = t_ph[i];
-#endif
     }
 }
 
@@ -611,35 +673,6 @@ __device__ static inline void moments_add(double* __restrict__ m, const double o
     m[16] += (a0 * a0 + a1 * a1) + a2 * a2;
     m[17] += (b0 * b0 + b1 * b1) + b2 * b2;
     m[18] += d2;
-}
-
-// Fused hard stage + accumulation of the device-resident ICP loop.  Partial moments meet in 64-bit FIXED-POINT
-// accumulators (value * 2^F, F chosen on the host so that N * R^2 * 2^F < 2^61): integer additions commute, so
-// any number of waves may add in any order -- atomics, no slabs, no second kernel -- and the totals are still bitwise
-// reproducible.  Each wave total / hard item is rounded to 2^-F once (<= (waves + items) * 2^-F on a sum bounded by
-// N R^2: ~1e-14 relative, two orders above binary64 round-off and five below the parity bar).
-// Accumulator sets: atomics to one cache line serialise at its L2 channel (~100 ns each), so the ~60 000 atomics of a pass are
-// spread over 1024 sets = 2 560 lines (64 sets measured 52 us for the fused kernel, i.e. ~35 us of queued atomics)
-#ifndef PCR_ACC_SETS
-#define PCR_ACC_SETS 64
-#endif
-constexpr int ACC_SETS = PCR_ACC_SETS;
-struct hard_acc_args {
-    int acc_blocks;                       // 0: plain hard stage (nn1 API, host loop)
-    const pcr_pt* q;                      // the source, already transformed in place by the tile kernel
-    const unsigned int* open_mask;        // per wave tile: which queries the hard stage owns
-    unsigned long long* acc;              // [ACC_SETS][PCR_NMOM], zero on entry, zeroed again by the finishing block
-    unsigned int* ticket;
-    wt_xyz* prev_xyz;
-    double scale, inv_scale;              // 2^F, 2^-F
-    pcr_icp_dev_state* st;
-    pcr_icp_loop_args la;
-};
-
-// lanes 0..18 of the calling wave add one moment each (one vector atomic instruction); mk = this lane's moment
-__device__ static inline void acc_fixed_add(unsigned long long* __restrict__ acc, unsigned int set, int lane, double mk, double scale) {
-    if (lane < PCR_NMOM - 1 && mk != 0.0)
-        atomicAdd(acc + (size_t)(set % ACC_SETS) * PCR_NMOM + lane, (unsigned long long)__double2ll_rn(mk * scale));   // two's complement
 }
 
 // -------------------------------------------------------------- hard stage
@@ -764,59 +797,126 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
     }
 }
 
+// Searches one query exactly: pruned descent of the nested cell hierarchy by the 64 lanes of the calling wave.
+// `bound2` bounds the search from above (gate and / or the tile stage's candidate, DBL_MAX = nothing); `have_cand` says a
+// real point lies inside it.  On return every lane holds the same (bd2, bid, bpos); POS_NONE = nothing inside the bound.
+__device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard_lds* L, const int lane, const double ax, const double ay, const double az,
+                                                   double bound2, bool have_cand, double& bd2, long long& bid, unsigned int& bpos,
+                                                   unsigned int& h_steps, unsigned int& h_pts, int& s_level0) {
+    const int top = gv.levels - 1;
+    bd2 = DBL_MAX;
+    bid = ID_NONE;
+    bpos = POS_NONE;
+    bool clamped = false;
+    const int cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
+    const int cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
+    const int cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
+    if (!clamped && !have_cand) {
+        // nothing known yet (tile too large to stage): the query's own level-0 cell gives a first bound
+        unsigned int s, e;
+        if (lookup_cell(gv.table[0], gv.mask[0], (unsigned int)cx, (unsigned int)cy, (unsigned int)cz, &s, &e)) {
+            scan_range(gv.pts, s + lane, e, 64, ax, ay, az, bd2, bid, bpos);
+            bound2 = fmin(bound2, wave_min(bd2));
+        }
+    }
+    // Level schedule.  With a real candidate in hand the search starts at the smallest level whose
+    // 3x3x3 block covers the bound ball.  Without one (only the gate, or nothing, bounds the search)
+    // it starts at level 0 and grows: the first candidate found shrinks the ball, usually long before
+    // the block would have to cover the whole gate radius in a dense part of the scan.
+    auto level_for = [&](double b2, int from) {
+        double c = gv.cell0 * (double)(1ll << (2 * from));
+        for (int l = from; l <= top; ++l) {
+            const double safe = c * (1.0 - 1e-9);
+            if (safe * safe >= b2) return l;
+            c *= 4.0;
+        }
+        return top + 1;  // not even the top level's block covers the ball
+    };
+    have_cand = have_cand || __any(bd2 < DBL_MAX);
+    int s_level = clamped ? top + 1 : (have_cand ? level_for(bound2, 0) : 0);
+    s_level0 = s_level;
+    int sp = 0;  // wave-uniform stack pointer
+    while (s_level <= top) {
+        const int lvl = s_level;
+        const double cell = gv.cell0 * (double)(1ll << (2 * lvl));
+        bool valid = lane < 27;
+        const int X = (cx >> (2 * lvl)) + (lane % 3 - 1), Y = (cy >> (2 * lvl)) + ((lane / 3) % 3 - 1), Z = (cz >> (2 * lvl)) + (lane / 9 - 1);
+        const int lim = (int)(PCR_COORD_MAX >> (2 * lvl));
+        valid = valid && X >= 0 && Y >= 0 && Z >= 0 && X <= lim && Y <= lim && Z <= lim;
+        unsigned int s = 0, e = 0;
+        double bdist = 0.0;
+        if (valid) {
+            bdist = box_dist2(gv, lvl, cell, (unsigned int)X, (unsigned int)Y, (unsigned int)Z, ax, ay, az);
+            valid = bdist <= bound2 && lookup_cell(gv.table[lvl], gv.mask[lvl], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &s, &e);
+        }
+        hard_disperse(gv, L, sp, lane, valid, s, e, (unsigned int)X, (unsigned int)Y, (unsigned int)Z, lvl, bdist, ax, ay, az, bd2, bid, bpos,
+                      bound2, h_pts);
+        ++h_steps;
+        while (sp > 0) {
+            --sp;
+            const hard_entry en = L->stack[sp];  // same address in every lane: LDS broadcast
+            const double ecell = gv.cell0 * (double)(1ll << (2 * en.level));
+            if (box_dist2(gv, en.level, ecell, en.x, en.y, en.z, ax, ay, az) > bound2) continue;
+            // split: one child per lane, box test against the bound, probe
+            const int cl = en.level - 1;
+            const unsigned int CX = en.x * 4u + (lane & 3), CY = en.y * 4u + ((lane >> 2) & 3), CZ = en.z * 4u + (lane >> 4);
+            const double cdist = box_dist2(gv, cl, ecell * 0.25, CX, CY, CZ, ax, ay, az);
+            unsigned int cs = 0, ce = 0;
+            const bool cvalid = cdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], CX, CY, CZ, &cs, &ce);
+            hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+            ++h_steps;
+        }
+        const double safe = cell * (1.0 - 1e-9);
+        if (safe * safe >= bound2) break;  // the block just searched covers the bound ball: exact
+        s_level = (bound2 < DBL_MAX) ? level_for(bound2, lvl + 1) : lvl + 1;
+    }
+    if (s_level > top) {
+        // the ball is not covered by any level's 3x3x3 block (query far outside the grid, or no bound at all):
+        // descend from the <= 8 root cells that hold the whole target
+        const double cell = gv.cell0 * (double)(1ll << (2 * top));
+        const int b0 = (int)(PCR_COORD_BIAS >> (2 * top));
+        bool valid = lane < 8;
+        const unsigned int X = b0 + (lane & 1), Y = b0 + ((lane >> 1) & 1), Z = b0 + ((lane >> 2) & 1);
+        unsigned int s = 0, e = 0;
+        double bdist = 0.0;
+        if (valid) {
+            bdist = box_dist2(gv, top, cell, X, Y, Z, ax, ay, az);
+            valid = bdist <= bound2 && lookup_cell(gv.table[top], gv.mask[top], X, Y, Z, &s, &e);
+        }
+        hard_disperse(gv, L, sp, lane, valid, s, e, X, Y, Z, top, bdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+        ++h_steps;
+        while (sp > 0) {
+            --sp;
+            const hard_entry en = L->stack[sp];
+            const double ecell = gv.cell0 * (double)(1ll << (2 * en.level));
+            if (box_dist2(gv, en.level, ecell, en.x, en.y, en.z, ax, ay, az) > bound2) continue;
+            const int cl = en.level - 1;
+            const unsigned int CX = en.x * 4u + (lane & 3), CY = en.y * 4u + ((lane >> 2) & 3), CZ = en.z * 4u + (lane >> 4);
+            const double cdist = box_dist2(gv, cl, ecell * 0.25, CX, CY, CZ, ax, ay, az);
+            unsigned int cs = 0, ce = 0;
+            const bool cvalid = cdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], CX, CY, CZ, &cs, &ce);
+            hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+            ++h_steps;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od2 = __shfl_xor(bd2, off, 64);
+        const long long oid = __shfl_xor(bid, off, 64);
+        const unsigned int opos = __shfl_xor(bpos, off, 64);
+        if (better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; bpos = opos; }
+    }
+}
+
 // (115 VGPRs -> 4 waves per SIMD; forcing 5, 6 or 8 with amdgpu_waves_per_eu spills and measured 31, 39, 50 us against 29)
 __global__ void __launch_bounds__(256)
 grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const unsigned int* __restrict__ count_p, long long nq, double max_d2, int gated,
                  unsigned int* __restrict__ res_pos, double* __restrict__ res_d2, unsigned long long* __restrict__ dbg,
-                 const pcr_icp_dev_state* __restrict__ st, hard_acc_args A) {
+                 const pcr_icp_dev_state* __restrict__ st) {
     __shared__ hard_lds s_lds[4];
     if (st && st->stop) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     hard_lds* L = &s_lds[wave];
-    if ((int)blockIdx.x < A.acc_blocks) {
-        // Phase P: the moments of the queries the wave tiles PROVED (their open_mask bit is clear), four per thread; they do
-        // not depend on the hard stage, so they are accumulated while the other blocks already walk the hard lists
-        double m[PCR_NMOM];
-#pragma unroll
-        for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
-        const long long stride = (long long)A.acc_blocks * blockDim.x;
-        for (long long q0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < nq; q0 += 4 * stride) {
-            unsigned int pos[4];
-            pcr_pt p[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long long qi = q0 + u * stride;
-                pos[u] = POS_NONE;
-                if (qi < nq) {
-                    const unsigned int mk = A.open_mask[qi / WT_Q];
-                    if (!((mk >> (unsigned int)(qi % WT_Q)) & 1u)) pos[u] = res_pos[qi];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long long qi = q0 + u * stride;
-                if (qi < nq) p[u] = A.q[qi];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (pos[u] != POS_NONE) b[u] = gv.pts[pos[u]];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (pos[u] == POS_NONE) continue;
-                A.prev_xyz[q0 + u * stride] = wt_xyz{b[u].x, b[u].y, b[u].z};   // seed of the next pass's wave tiles
-                moments_add(m, gv.origin, p[u].x, p[u].y, p[u].z, b[u], max_d2, gated);
-            }
-        }
-        double* xch = reinterpret_cast<double*>(L);   // this wave's LDS slice: 19 totals from lane 63 to lanes 0..18
-#pragma unroll
-        for (int k = 0; k < PCR_NMOM - 1; ++k) {
-            const double tot = wave_total_f64(m[k]);   // fixed order inside the wave
-            if (lane == 63) xch[k] = tot;
-        }
-        wave_sync();
-        acc_fixed_add(A.acc, blockIdx.x * 4u + (unsigned int)wave, lane, lane < PCR_NMOM - 1 ? xch[lane] : 0.0, A.scale);
-        wave_sync();
-    }
     // exclusive prefix of the sub-list lengths (lanes 0..H_NLIST-1 hold one list each)
     unsigned int l_cnt = lane < H_NLIST ? count_p[H_CSTRIDE * lane] : 0u;
     unsigned int l_inc = l_cnt;
@@ -828,138 +928,20 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
     const unsigned int count = __shfl(l_inc, H_NLIST - 1, 64);
     const unsigned int l_exc = l_inc - l_cnt;
     const unsigned int l_cap = hard_list_cap(nq);
-    const int top = gv.levels - 1;
-    // (the blocks that accumulated the proven queries above do not take hard items: they would start them ~6 us late and
-    // become the kernel's tail)
-    const unsigned int hgrid = gridDim.x - (unsigned int)A.acc_blocks;
-    for (unsigned int w = ((int)blockIdx.x < A.acc_blocks ? count : (blockIdx.x - (unsigned int)A.acc_blocks) * 4 + wave); w < count; w += hgrid * 4) {
+    for (unsigned int w = blockIdx.x * 4 + wave; w < count; w += gridDim.x * 4) {
         const int hl = (int)__ffsll((long long)__ballot(lane < H_NLIST && l_exc <= w && w < l_exc + l_cnt)) - 1;  // exactly one list holds item w
         const work_item it = list[(size_t)hl * l_cap + (w - __shfl(l_exc, hl, 64))];
         const unsigned long long h_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
         unsigned int h_steps = 0, h_pts = 0;
-        const double ax = it.ax, ay = it.ay, az = it.az;
-        double bd2 = DBL_MAX;
-        long long bid = ID_NONE;
-        unsigned int bpos = POS_NONE;
+        int s_level0 = 0;
+        double bd2;
+        long long bid;
+        unsigned int bpos;
         // it.best_d2 is an UPPER bound of the tile stage's candidate's squared distance: it bounds the search, and the candidate
         // itself is met again by the scan (it lies inside the bound) -- reading its record here would be one more dependent
         // memory round trip in a chain of four
-        double bound2 = gated ? fmin(it.best_d2, max_d2) : it.best_d2;  // DBL_MAX when nothing bounds the search
-        bool clamped = false;
-        const int cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
-        const int cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
-        const int cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
-        if (!clamped && it.best_pos == POS_NONE) {
-            // nothing known yet (tile too large to stage): the query's own level-0 cell gives a first bound
-            unsigned int s, e;
-            if (lookup_cell(gv.table[0], gv.mask[0], (unsigned int)cx, (unsigned int)cy, (unsigned int)cz, &s, &e)) {
-                scan_range(gv.pts, s + lane, e, 64, ax, ay, az, bd2, bid, bpos);
-                bound2 = fmin(bound2, wave_min(bd2));
-            }
-        }
-        // Level schedule.  With a real candidate in hand the search starts at the smallest level whose
-        // 3x3x3 block covers the bound ball.  Without one (only the gate, or nothing, bounds the search)
-        // it starts at level 0 and grows: the first candidate found shrinks the ball, usually long before
-        // the block would have to cover the whole gate radius in a dense part of the scan.
-        auto level_for = [&](double b2, int from) {
-            double c = gv.cell0 * (double)(1ll << (2 * from));
-            for (int l = from; l <= top; ++l) {
-                const double safe = c * (1.0 - 1e-9);
-                if (safe * safe >= b2) return l;
-                c *= 4.0;
-            }
-            return top + 1;  // not even the top level's block covers the ball
-        };
-        const bool have_cand = it.best_pos != POS_NONE || __any(bd2 < DBL_MAX);
-        int s_level = clamped ? top + 1 : (have_cand ? level_for(bound2, 0) : 0);
-        const int s_level0 = s_level;
-        int sp = 0;  // wave-uniform stack pointer
-        while (s_level <= top) {
-            const int lvl = s_level;
-            const double cell = gv.cell0 * (double)(1ll << (2 * lvl));
-            bool valid = lane < 27;
-            const int X = (cx >> (2 * lvl)) + (lane % 3 - 1), Y = (cy >> (2 * lvl)) + ((lane / 3) % 3 - 1), Z = (cz >> (2 * lvl)) + (lane / 9 - 1);
-            const int lim = (int)(PCR_COORD_MAX >> (2 * lvl));
-            valid = valid && X >= 0 && Y >= 0 && Z >= 0 && X <= lim && Y <= lim && Z <= lim;
-            unsigned int s = 0, e = 0;
-            double bdist = 0.0;
-            if (valid) {
-                bdist = box_dist2(gv, lvl, cell, (unsigned int)X, (unsigned int)Y, (unsigned int)Z, ax, ay, az);
-                valid = bdist <= bound2 && lookup_cell(gv.table[lvl], gv.mask[lvl], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &s, &e);
-            }
-            hard_disperse(gv, L, sp, lane, valid, s, e, (unsigned int)X, (unsigned int)Y, (unsigned int)Z, lvl, bdist, ax, ay, az, bd2, bid, bpos,
-                          bound2, h_pts);
-            ++h_steps;
-            while (sp > 0) {
-                --sp;
-                const hard_entry en = L->stack[sp];  // same address in every lane: LDS broadcast
-                const double ecell = gv.cell0 * (double)(1ll << (2 * en.level));
-                if (box_dist2(gv, en.level, ecell, en.x, en.y, en.z, ax, ay, az) > bound2) continue;
-                // split: one child per lane, box test against the bound, probe
-                const int cl = en.level - 1;
-                const unsigned int CX = en.x * 4u + (lane & 3), CY = en.y * 4u + ((lane >> 2) & 3), CZ = en.z * 4u + (lane >> 4);
-                const double cdist = box_dist2(gv, cl, ecell * 0.25, CX, CY, CZ, ax, ay, az);
-                unsigned int cs = 0, ce = 0;
-                const bool cvalid = cdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], CX, CY, CZ, &cs, &ce);
-                hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
-                ++h_steps;
-            }
-            const double safe = cell * (1.0 - 1e-9);
-            if (safe * safe >= bound2) break;  // the block just searched covers the bound ball: exact
-            s_level = (bound2 < DBL_MAX) ? level_for(bound2, lvl + 1) : lvl + 1;
-        }
-        if (s_level > top) {
-            // the ball is not covered by any level's 3x3x3 block (query far outside the grid, or no bound at all):
-            // descend from the <= 8 root cells that hold the whole target
-            const double cell = gv.cell0 * (double)(1ll << (2 * top));
-            const int b0 = (int)(PCR_COORD_BIAS >> (2 * top));
-            bool valid = lane < 8;
-            const unsigned int X = b0 + (lane & 1), Y = b0 + ((lane >> 1) & 1), Z = b0 + ((lane >> 2) & 1);
-            unsigned int s = 0, e = 0;
-            double bdist = 0.0;
-            if (valid) {
-                bdist = box_dist2(gv, top, cell, X, Y, Z, ax, ay, az);
-                valid = bdist <= bound2 && lookup_cell(gv.table[top], gv.mask[top], X, Y, Z, &s, &e);
-            }
-            hard_disperse(gv, L, sp, lane, valid, s, e, X, Y, Z, top, bdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
-            ++h_steps;
-            while (sp > 0) {
-                --sp;
-                const hard_entry en = L->stack[sp];
-                const double ecell = gv.cell0 * (double)(1ll << (2 * en.level));
-                if (box_dist2(gv, en.level, ecell, en.x, en.y, en.z, ax, ay, az) > bound2) continue;
-                const int cl = en.level - 1;
-                const unsigned int CX = en.x * 4u + (lane & 3), CY = en.y * 4u + ((lane >> 2) & 3), CZ = en.z * 4u + (lane >> 4);
-                const double cdist = box_dist2(gv, cl, ecell * 0.25, CX, CY, CZ, ax, ay, az);
-                unsigned int cs = 0, ce = 0;
-                const bool cvalid = cdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], CX, CY, CZ, &cs, &ce);
-                hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
-                ++h_steps;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double od2 = __shfl_xor(bd2, off, 64);
-            const long long oid = __shfl_xor(bid, off, 64);
-            const unsigned int opos = __shfl_xor(bpos, off, 64);
-            if (better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; bpos = opos; }
-        }
-        if (A.acc && bpos != POS_NONE) {   // wave-uniform: after the merge every lane holds the same result
-            double* xch = reinterpret_cast<double*>(L->fl_off);   // 19 moments from lane 0 to lanes 0..18 (fl_off/fl_start: 512 B, free here)
-            if (lane == 0) {
-                const pcr_pt b = gv.pts[bpos];
-                A.prev_xyz[it.qi] = wt_xyz{b.x, b.y, b.z};
-                double m[PCR_NMOM];
-#pragma unroll
-                for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
-                moments_add(m, gv.origin, ax, ay, az, b, max_d2, gated);
-#pragma unroll
-                for (int k = 0; k < PCR_NMOM - 1; ++k) xch[k] = m[k];
-            }
-            wave_sync();
-            acc_fixed_add(A.acc, w, lane, lane < PCR_NMOM - 1 ? xch[lane] : 0.0, A.scale);
-            wave_sync();
-        }
+        hard_search(gv, L, lane, it.ax, it.ay, it.az, gated ? fmin(it.best_d2, max_d2) : it.best_d2, it.best_pos != POS_NONE, bd2, bid, bpos, h_steps,
+                    h_pts, s_level0);
         if (lane == 0) {
             res_pos[it.qi] = bpos;
             if (res_d2) res_d2[it.qi] = bd2;
@@ -971,63 +953,372 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
             }
         }
     }
-    if (!A.acc) return;
-    // ---- the block that arrives last converts the totals, solves the Procrustes step and tests convergence.
-    // Hand-off: the only data the finishing block reads from other blocks are the accumulators, and those are touched by
-    // device-scope atomics alone (performed at the coherence point, no cache to flush).  So a block only waits for its own
-    // atomics to be acknowledged (vmcnt) and takes a ticket with a relaxed atomic -- NO agent-scope release fence: on this
-    // chip that fence writes back the XCD's L2, and 2048 blocks doing it cost 40 us.  (res_pos / prev_xyz stores are for the
-    // NEXT kernel; the kernel boundary publishes them.)
-    __shared__ unsigned int s_last;
-    __shared__ double s_m[PCR_NMOM];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // two-level ticket: a returning atomic on ONE word serialises at ~88 per us (2048 blocks: 23 us).  Block b takes a
-        // ticket of group b % 32 (64 bytes apart); the last arriver of a group takes one of the root ticket; the last of those finishes.
-        const unsigned int ngroups = gridDim.x < 32u ? gridDim.x : 32u;
-        const unsigned int g = blockIdx.x % ngroups;
-        const unsigned int gsize = gridDim.x / ngroups + (g < gridDim.x % ngroups ? 1u : 0u);
-        unsigned int* gt = A.ticket + 16u * (1u + g);
-        s_last = 0u;
-        if (__hip_atomic_fetch_add(gt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
-            __hip_atomic_store(gt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) {
-                s_last = 1u;
-                __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+}
+
+// ------------------------------------------------------------------------------------------------ one-kernel ICP pass
+// One launch per ICP iteration of the device-resident loop: every wave runs its tile, adds the moments of the queries it
+// proved, hands what it could not prove to a work queue, then serves that queue (one query per wave, hard_search) until
+// its group of tiles has nothing left; the wave that leaves last solves the Procrustes step.  Against tile kernel ->
+// hard kernel this removes a launch boundary and, more important, the hard items start while slow tiles are still
+// running (the tile stage is one generation of waves: its tail left most of the chip idle).
+//
+// Moments meet in 64-bit FIXED-POINT accumulators (value * 2^F, F chosen on the host so that N * R^2 * 2^F < 2^61):
+// integer additions commute, so waves may add in any order -- device-scope atomics, no slabs -- and the totals are still
+// bitwise reproducible.  Each wave total / hard item is rounded to 2^-F once (<= (waves + items) * 2^-F on a sum bounded
+// by N R^2: ~1e-14 relative, two orders above binary64 round-off and five below the parity bar).  64 sets of 20 words:
+// 1024 sets made the finishing read 14 us slower, one set serialises the atomics at their L2 channel.
+//
+// Everything waves tell each other INSIDE the launch goes through device-scope atomics (performed at the coherence
+// point: the L2 of another XCD never holds a stale copy) and never needs a fence (an agent-scope release is an L2
+// write-back on this chip: 2048 blocks doing one cost 40 us):
+//   queue     32 groups (tile t belongs to group t % 32).  Per group ONE 64-bit word
+//                 done << 44 | claimed << 22 | reserved
+//             (tiles of the group through with their tile stage; slot indices handed out; slots reserved).  A tile reserves
+//             its slots and reports itself done with ONE returning add, then stores its items; every 8-byte word of an item is
+//             self-validating (all-ones = not written yet; the consumer puts that back), so no ordering between the words or
+//             against the counter is needed.
+//   claims    a free wave takes the NEXT slot index with one returning add -- whether or not an item is there yet -- and
+//             then polls ITS OWN slot: waiting waves sit on private addresses, an item lands in front of the wave that
+//             serves it, and the group word only sees one add per tile and per claim.  (Polling the group word and claiming
+//             by compare-and-swap measured 430 us per pass with 117 waves per word, 88 us with 15: same-address accesses
+//             serialise at the memory side at ~100 ns each, and few waves per group balance badly.)  The tile that reports
+//             done last knows the final slot count R and POISONS the slots [R, R + tiles of the group): every wave still
+//             waiting (each holds exactly one index >= R) reads that and leaves.
+//   waiting   holding an index means waiting for it, and a wave may only WAIT if every tile of its group has started (they
+//             are resident and will finish): on a busy GPU (several pairs in flight, clouds of several wave generations)
+//             waiting waves would keep the slots the missing tiles need.  Until the group has started completely a free
+//             wave therefore only takes items that are already there (compare-and-swap while claimed < reserved) and
+//             leaves otherwise.  Progress: the tile that finishes last drains the queue itself.
+//   finish    vmcnt(0) (own atomics acknowledged), then a two-level ticket (one word per group, then a root).
+#ifndef PCR_ACC_SETS
+#define PCR_ACC_SETS 64
+#endif
+constexpr int ACC_SETS = PCR_ACC_SETS;
+#ifndef PCR_PASS_GROUPS
+#define PCR_PASS_GROUPS 32
+#endif
+constexpr int PASS_GROUPS = PCR_PASS_GROUPS;
+constexpr int PASS_SYNC_STRIDE = 32;                      // 64-bit words per group: queue word at 0, started at 16, ticket at 17 (other line)
+constexpr int PASS_SYNC_WORDS = PASS_SYNC_STRIDE * (PASS_GROUPS + 1);   // + root ticket (0) / error word (16)
+constexpr unsigned long long ITEM_NONE = ~0ull, ITEM_POISON = ~0ull - 1ull;   // neither is a valid last word of an item (query index 2^32 - 1 / 2^32 - 2)
+constexpr unsigned int PASS_SPIN_LIMIT = 1u << 18;        // polls before a wave gives up and flags an error (never seen)
+constexpr int Q_BITS = 22;                                // reserved / claimed fields; done has the upper 20 bits
+constexpr unsigned long long Q_MASK = (1ull << Q_BITS) - 1ull;
+constexpr long long PASS_MAX_NQ = 1ll << 26;              // 32 groups x 2^22 slots, with room for the poison range
+struct pass_args {
+    unsigned long long* items;            // [PASS_GROUPS][cap][4], all-ones between launches
+    unsigned long long* sync;             // [PASS_GROUPS + 1][PASS_SYNC_STRIDE], zero between launches
+    unsigned int cap;
+    unsigned long long* acc;              // [ACC_SETS][PCR_NMOM], zero between launches
+    wt_xyz* prev_xyz;
+    double scale, inv_scale;              // 2^F, 2^-F
+    pcr_icp_dev_state* st;
+    pcr_icp_loop_args la;
+};
+__host__ __device__ static inline unsigned int pass_item_cap(long long nq) {   // room for every query of the group's tiles
+    const long long tiles = (nq + WT_Q - 1) / WT_Q + 4;
+    return (unsigned int)(((tiles + PASS_GROUPS - 1) / PASS_GROUPS) * (WT_Q + 1));   // + the poison range
+}
+
+// lanes 0..18 of the calling wave add one moment each (one vector atomic instruction); mk = this lane's moment
+__device__ static inline void acc_fixed_add(unsigned long long* __restrict__ acc, unsigned int set, int lane, double mk, double scale) {
+    if (lane < PCR_NMOM - 1 && mk != 0.0)
+        atomicAdd(acc + (size_t)(set % ACC_SETS) * PCR_NMOM + lane, (unsigned long long)__double2ll_rn(mk * scale));   // two's complement
+}
+
+__device__ static inline unsigned long long ld_dev(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static inline void st_dev(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+union pass_lds {
+    wtile_lds t;
+    hard_lds h;
+    double xch[WT_Q * (PCR_NMOM - 1)];
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
+grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, double max_d2, int xcd_remap,
+                 unsigned int pcap, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg, int use_prev, pass_args A) {
+    __shared__ pass_lds s_lds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int tile = wtile_block(xcd_remap) * 4 + wave;
+    // the tile's records and the loop state are requested together; a pass enqueued behind a stop leaves before any side effect
+    wt_pre P;
+    wtile_preload(tile, lane, q, nq, res_pos, use_prev ? A.prev_xyz : nullptr, P);
+    const pcr_xform x = A.st->x;
+    if (A.st->stop) return;
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long rt_start = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    unsigned long long rt_tile = 0, rt_acc = 0;
+    unsigned int n_items = 0, n_polls = 0, n_casfail = 0;
+    pass_lds* L = &s_lds[wave];
+    const unsigned int n_waves = gridDim.x * 4;
+    const unsigned int g = tile % PASS_GROUPS;
+    const unsigned int g_tiles = n_waves / PASS_GROUPS + (g < n_waves % PASS_GROUPS ? 1u : 0u);
+    unsigned long long* const g_q = A.sync + (size_t)PASS_SYNC_STRIDE * g;   // done << 44 | claimed << 22 | reserved
+    unsigned long long* const g_started = g_q + 16;
+    unsigned long long* const g_ticket = g_q + 17;
+    unsigned long long* const items = A.items + (size_t)g * A.cap * 4;
+    if (lane == 0) __hip_atomic_fetch_add(g_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody waits for the reply
+    // ---- tile
+    wt_state S;
+    wtile_search(*gvp, &L->t, tile, lane, P, q, nq, x, 1, 1, max_d2, 1, pcap, res_pos, nullptr, dbg, use_prev ? A.prev_xyz : nullptr, S);
+    wave_sync();
+    if (dbg) rt_tile = __builtin_amdgcn_s_memrealtime();
+    // ---- leave the tile stage.  Requested together: the target records of the proven queries (for the moments) and the
+    // group's started count; then ONE returning add reserves the slots of the open queries, reports the tile done and --
+    // when the whole group has started, so that waiting is allowed -- already claims this wave's first slot to serve.
+    const bool proven = lane < WT_Q && S.won != POS_NONE;
+    pcr_pt nb;
+    nb.x = nb.y = nb.z = 0.0; nb.id = 0;
+    const bool nb_known = proven && S.won == P.seed_pos;   // same neighbour as in the last pass: its coordinates came with the seed
+    if (proven && !nb_known) nb = as_global(gv.pts)[S.won];
+    bool all_started = false;
+    {
+        unsigned long long sv = 0;
+        if (lane == 0) sv = ld_dev(g_started);
+        all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)sv) == g_tiles;
+    }
+    const bool unres = S.open && lane < WT_Q;
+    const unsigned long long um = __ballot(unres);
+    unsigned int mine = 0;     // slot index this wave owns (claimed below, or in the loop)
+    bool have_claim = false, group_done = false;
+    {
+        unsigned long long old = 0;
+        if (lane == 0)
+            old = __hip_atomic_fetch_add(g_q, (1ull << (2 * Q_BITS)) | (all_started ? 1ull << Q_BITS : 0ull) | (unsigned long long)__popcll(um), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int o_lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)old), o_hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(old >> 32));
+        old = ((unsigned long long)o_hi << 32) | o_lo;
+        const unsigned int base = (unsigned int)(old & Q_MASK);
+        const unsigned int done_before = (unsigned int)(old >> (2 * Q_BITS));
+        if (unres) {
+            unsigned long long* it = items + (size_t)(base + __popcll(um & ((1ull << lane) - 1ull))) * 4;
+            const bool cand = !S.clamped && S.cand_pos != POS_NONE;
+            // a NaN coordinate must not look like "not written yet"
+            st_dev(it + 0, S.ax == S.ax ? (unsigned long long)__double_as_longlong(S.ax) : 0x7ff8000000000000ull);
+            st_dev(it + 1, S.ay == S.ay ? (unsigned long long)__double_as_longlong(S.ay) : 0x7ff8000000000000ull);
+            st_dev(it + 2, S.az == S.az ? (unsigned long long)__double_as_longlong(S.az) : 0x7ff8000000000000ull);
+            st_dev(it + 3, (unsigned long long)(unsigned int)S.qi | ((unsigned long long)__float_as_uint(cand ? S.bound2 : INFINITY) << 32));
+        }
+        const unsigned int R = base + (unsigned int)__popcll(um);
+        if (done_before == g_tiles - 1u) {
+            // last tile of the group: no slot beyond R will ever be filled; whoever holds one reads this and leaves
+            for (unsigned int k = lane; k < g_tiles; k += 64) st_dev(items + (size_t)(R + k) * 4 + 3, ITEM_POISON);
+            group_done = true;
+        }
+        if (all_started) {
+            have_claim = true;
+            mine = (unsigned int)((old >> Q_BITS) & Q_MASK);
+        }
+        group_done = group_done && have_claim && mine >= R;   // ... and every slot below R already has its wave: nothing left for this one
+    }
+    // ---- moments of the proven queries: 19 moments per query through the wave's LDS slice, lanes 0..18 add them in query order
+    {
+        double m[PCR_NMOM];
+#pragma unroll
+        for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+        if (proven) {
+            if (nb_known) { nb.x = P.seed_b.x; nb.y = P.seed_b.y; nb.z = P.seed_b.z; }
+            else A.prev_xyz[S.qi] = wt_xyz{nb.x, nb.y, nb.z};   // seed of the next pass's tile
+            moments_add(m, gv.origin, S.ax, S.ay, S.az, nb, max_d2, 1);
+        }
+        if (lane < WT_Q) {
+#pragma unroll
+            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xch[lane * (PCR_NMOM - 1) + k] = m[k];
+        }
+        wave_sync();
+        double tot = 0.0;
+        if (lane < PCR_NMOM - 1) {
+#pragma unroll 8
+            for (int j = 0; j < WT_Q; ++j) tot += L->xch[j * (PCR_NMOM - 1) + lane];
+        }
+        acc_fixed_add(A.acc, tile, lane, tot, A.scale);
+        wave_sync();
+    }
+    if (dbg && lane == 0) {
+        atomicAdd(&dbg[blockIdx.x * 4 + 1], S.dbg_pairs);
+        atomicAdd(&dbg[blockIdx.x * 4 + 2], (unsigned long long)S.dbg_passes);
+        atomicAdd(&dbg[blockIdx.x * 4 + 3], (unsigned long long)__popcll(um));
+        atomicMax(&dbg[blockIdx.x * 4 + 0], __builtin_amdgcn_s_memtime() - t_start);
+    }
+    if (dbg) rt_acc = __builtin_amdgcn_s_memrealtime();
+    // ---- serve the group's queue
+    bool failed = false;
+    while (!group_done) {
+        if (!have_claim) {
+            if (!all_started) {
+                unsigned long long sv = 0;
+                if (lane == 0) sv = ld_dev(g_started);
+                all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)sv) == g_tiles;
+            }
+            if (all_started) {
+                unsigned long long old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(g_q, 1ull << Q_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int o_lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)old), o_hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(old >> 32));
+                old = ((unsigned long long)o_hi << 32) | o_lo;
+                mine = (unsigned int)((old >> Q_BITS) & Q_MASK);
+                if ((unsigned int)(old >> (2 * Q_BITS)) == g_tiles && mine >= (unsigned int)(old & Q_MASK)) break;   // group done, nothing left
+            } else {
+                // tiles of the group are not resident yet: take what is there, never hold a slot waiting for them
+                unsigned long long qw = 0;
+                if (lane == 0) qw = ld_dev(g_q);
+                const unsigned int q_lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)qw), q_hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(qw >> 32));
+                qw = ((unsigned long long)q_hi << 32) | q_lo;
+                mine = (unsigned int)((qw >> Q_BITS) & Q_MASK);
+                if (mine >= (unsigned int)(qw & Q_MASK)) break;
+                int got = 0;
+                if (lane == 0) {
+                    unsigned long long expect = qw;
+                    got = __hip_atomic_compare_exchange_strong(g_q, &expect, qw + (1ull << Q_BITS), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                }
+                if (!__builtin_amdgcn_readfirstlane(got)) { ++n_casfail; continue; }   // somebody else moved the word: look again
             }
         }
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x < H_NLIST) const_cast<unsigned int*>(count_p)[H_CSTRIDE * threadIdx.x] = 0;   // next search starts with empty lists
-    // ACC_SETS x 20 words: independent loads, 8 per thread and step, summed as integers (order irrelevant), zeroed for the next pass
-    __shared__ unsigned long long s_tot[PCR_NMOM];
-    if (threadIdx.x < PCR_NMOM) s_tot[threadIdx.x] = 0ull;
-    __syncthreads();
-    {
-        // thread t owns words t, t + 256, ...; 256 = 12 * 20 + 16, so a thread's moment index walks through all 20 values:
-        // keep one running sum per thread and moment residue instead -> simpler: add every word to its LDS total
-        constexpr int WORDS = ACC_SETS * PCR_NMOM;
-        for (int i0 = threadIdx.x; i0 < WORDS; i0 += 256 * 8) {
-            unsigned long long v[8];
+        have_claim = false;
+        // wait for the item (or the poison) in slot `mine`
+        unsigned long long* it = items + (size_t)mine * 4;
+        unsigned long long w = ITEM_NONE;
+        bool poisoned = false;
+        for (unsigned int spins = 0;; ++spins) {
+            if (lane < 4) w = ld_dev(it + lane);
+            const unsigned long long mk = __ballot(lane < 4 && w != ITEM_NONE);
+            poisoned = __builtin_amdgcn_readlane((int)(unsigned int)w, 3) == (int)(unsigned int)ITEM_POISON &&
+                       __builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), 3) == (int)(unsigned int)(ITEM_POISON >> 32);
+            if (poisoned || mk == 0xfull) break;
+            if (spins >= PASS_SPIN_LIMIT) { failed = true; break; }
+            ++n_polls;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (failed) break;
+        if (lane < 4 && w != ITEM_NONE) st_dev(it + lane, ITEM_NONE);   // the slot is clean for the next launch
+        if (poisoned) break;
+        ++n_items;
+        const unsigned int w_lo = (unsigned int)w, w_hi = (unsigned int)(w >> 32);
+        const double ax = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 0), __builtin_amdgcn_readlane((int)w_lo, 0));
+        const double ay = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 1), __builtin_amdgcn_readlane((int)w_lo, 1));
+        const double az = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 2), __builtin_amdgcn_readlane((int)w_lo, 2));
+        const unsigned int qi = (unsigned int)__builtin_amdgcn_readlane((int)w_lo, 3);
+        const float cand_b2 = __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)w_hi, 3));
+        const unsigned long long h_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+        unsigned int h_steps = 0, h_pts = 0;
+        int s_level0 = 0;
+        double bd2;
+        long long bid;
+        unsigned int bpos;
+        const bool have_cand = cand_b2 < INFINITY;
+        hard_search(gv, &L->h, lane, ax, ay, az, have_cand ? fmin((double)cand_b2, max_d2) : max_d2, have_cand, bd2, bid, bpos, h_steps, h_pts, s_level0);
+        wave_sync();
+        if (bpos != POS_NONE) {   // wave-uniform: after the merge every lane holds the same result
+            if (lane == 0) {
+                const pcr_pt b = as_global(gv.pts)[bpos];
+                A.prev_xyz[qi] = wt_xyz{b.x, b.y, b.z};
+                double m[PCR_NMOM];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)   // device-scope atomic loads: the words were only ever written by device-scope atomics
-                v[j] = (i0 + 256 * j < WORDS) ? __hip_atomic_load(A.acc + i0 + 256 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+                moments_add(m, gv.origin, ax, ay, az, b, max_d2, 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + 256 * j;
-                if (v[j]) {
-                    __hip_atomic_store(A.acc + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicAdd(&s_tot[i % PCR_NMOM], v[j]);
+                for (int k = 0; k < PCR_NMOM - 1; ++k) L->xch[k] = m[k];
+            }
+            wave_sync();
+            acc_fixed_add(A.acc, qi, lane, lane < PCR_NMOM - 1 ? L->xch[lane] : 0.0, A.scale);
+            wave_sync();
+        }
+        if (lane == 0) {
+            res_pos[qi] = bpos;
+            if (dbg) {
+                const unsigned int w_i = g + PASS_GROUPS * mine;
+                if (w_i < 60000) {
+                    dbg[(1 << 17) + w_i * 4 + 0] = __builtin_amdgcn_s_memtime() - h_t0;
+                    dbg[(1 << 17) + w_i * 4 + 1] = ((unsigned long long)h_steps << 32) | (unsigned int)((h_t0 - t_start) >> 4);
+                    dbg[(1 << 17) + w_i * 4 + 2] = h_pts;
+                    dbg[(1 << 17) + w_i * 4 + 3] = (unsigned long long)have_cand | ((unsigned long long)(s_level0 + 1) << 8);
                 }
             }
         }
     }
-    __syncthreads();
-    if (threadIdx.x < PCR_NMOM) s_m[threadIdx.x] = (double)(long long)s_tot[threadIdx.x] * A.inv_scale;
-    __syncthreads();
-    if (threadIdx.x == 0) pcr::icp_step(A.st, s_m, gv.origin, A.la);
+    const unsigned long long rt_loop = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    // ---- the wave that leaves last converts the totals, solves the Procrustes step and tests convergence
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* const root = A.sync + (size_t)PASS_SYNC_STRIDE * PASS_GROUPS;
+    int last = 0;
+    {
+        int g_last = 0;
+        unsigned long long qw = 0;
+        if (lane == 0) {
+            if (failed) st_dev(root + 16, 1ull);
+            if (__hip_atomic_fetch_add(g_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(g_tiles - 1u)) {
+                g_last = 1;
+                qw = ld_dev(g_q);
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane(g_last)) {
+            // everybody of the group is through with its words and slots: clean for the next launch (poison nobody read included)
+            const unsigned int R = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(qw & Q_MASK));
+            for (unsigned int k = lane; k < g_tiles; k += 64) st_dev(items + (size_t)(R + k) * 4 + 3, ITEM_NONE);
+            if (lane == 0) {
+                st_dev(g_q, 0ull);
+                st_dev(g_started, 0ull);
+                st_dev(g_ticket, 0ull);
+                const unsigned int n_groups = n_waves < (unsigned int)PASS_GROUPS ? n_waves : (unsigned int)PASS_GROUPS;
+                if (__hip_atomic_fetch_add(root, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n_groups - 1u)) {
+                    st_dev(root, 0ull);
+                    last = 1;
+                }
+            }
+        }
+    }
+    if (dbg && lane == 0) {
+        unsigned long long* d = dbg + (1 << 19) + (size_t)(blockIdx.x * 4 + wave) * 8;
+        d[0] = rt_start; d[1] = rt_tile; d[2] = rt_acc; d[3] = rt_loop; d[4] = n_items; d[5] = n_polls | ((unsigned long long)n_casfail << 32); d[6] = S.dbg_pairs | ((unsigned long long)S.dbg_passes << 40) | ((unsigned long long)__popcll(um) << 48); d[7] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+    // lane l < 60 owns moment l % 20 of every third set: independent loads, integer sums (order irrelevant), words zeroed behind.
+    // The head of the loop state travels with them (one 8-byte word per lane) into LDS: the Procrustes step reads and updates ~50
+    // of its words, and one lane going to global memory for them was a chain of dependent round trips (6.7 us for this block).
+    {
+        constexpr int HEAD_WORDS = (int)(pcr::ICP_STATE_HEAD_BYTES / 8);
+        static_assert(pcr::ICP_STATE_HEAD_BYTES % 8 == 0 && HEAD_WORDS <= 64, "state head: one word per lane");
+        double* const head = L->xch + 32;   // 16-byte aligned, behind the 20 moments
+        unsigned long long hw = 0;
+        if (lane < HEAD_WORDS) hw = reinterpret_cast<const unsigned long long*>(A.st)[lane];
+        const int mom = lane % PCR_NMOM, part = lane / PCR_NMOM;
+        long long sum = 0;
+        if (part < 3) {
+            constexpr int PER = (ACC_SETS + 2) / 3;
+            unsigned long long v[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int set = part + 3 * j;
+                v[j] = set < ACC_SETS ? ld_dev(A.acc + (size_t)set * PCR_NMOM + mom) : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int set = part + 3 * j;
+                if (v[j]) st_dev(A.acc + (size_t)set * PCR_NMOM + mom, 0ull);
+                sum += (long long)v[j];
+            }
+        }
+        if (dbg && lane == 0) dbg[(1 << 19) - 4] = __builtin_amdgcn_s_memrealtime();
+        sum += __shfl(sum, lane + PCR_NMOM, 64) + __shfl(sum, lane + 2 * PCR_NMOM, 64);   // lanes 0..19: all three parts
+        wave_sync();
+        if (dbg && lane == 0) dbg[(1 << 19) - 3] = __builtin_amdgcn_s_memrealtime();
+        if (lane < PCR_NMOM) L->xch[lane] = (double)sum * A.inv_scale;
+        if (lane < HEAD_WORDS) reinterpret_cast<unsigned long long*>(head)[lane] = hw;
+        wave_sync();
+        if (lane == 0) {
+            pcr_icp_dev_state* hs = reinterpret_cast<pcr_icp_dev_state*>(head);
+            if (ld_dev(root + 16)) { hs->status = PCR_E_HIP; hs->stop = 1; st_dev(root + 16, 0ull); }
+            else pcr::icp_step(hs, L->xch, gv.origin, A.la, A.st->r_diff, A.st->t_diff);
+        }
+        wave_sync();
+        if (dbg && lane == 0) dbg[(1 << 19) - 2] = __builtin_amdgcn_s_memrealtime();
+        if (lane < HEAD_WORDS) reinterpret_cast<unsigned long long*>(A.st)[lane] = reinterpret_cast<const unsigned long long*>(head)[lane];
+        if (dbg && lane == 0) dbg[(1 << 19) - 1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // --------------------------------------------------------------- epilogues
@@ -1170,7 +1461,7 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
     if (st) {
         // device-resident loop: Procrustes + convergence test here, the next pass reads st->x (kernel boundary orders it)
         __syncthreads();
-        if (threadIdx.x == 0) pcr::icp_step(st, s_m, gv.origin, la);
+        if (threadIdx.x == 0) pcr::icp_step(st, s_m, gv.origin, la, st->r_diff, st->t_diff);
     }
 }
 
@@ -1178,8 +1469,8 @@ grid_accumulate_kernel(pcr_grid_view gv, const pcr_pt* __restrict__ q, long long
 struct grid_scratch {
     unsigned int* res_pos = nullptr;
     double* res_d2 = nullptr;
-    unsigned int* open_mask = nullptr;  // [wave tiles]: bit i = query i of the tile went to the hard stage (device loop only)
-    unsigned long long* acc = nullptr;  // [ACC_SETS][PCR_NMOM] fixed-point moment accumulators (device loop only)
+    unsigned long long* acc = nullptr;  // [ACC_SETS][PCR_NMOM] fixed-point moment accumulators + [PASS_SYNC_WORDS] queue words (one-kernel pass only)
+    unsigned long long* items = nullptr;   // [PASS_GROUPS][pass_item_cap][4] work queue of the one-kernel pass
     void* prev_xyz = nullptr;         // [nq] x 24 B: coordinates of every query's neighbour of the last ICP pass (device loop only)
     work_item* hard_list = nullptr;   // [nq] worst case
     unsigned int* hard_count = nullptr;
@@ -1210,38 +1501,43 @@ static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
     if (sc->res_d2) pcr_dev_free(ctx, sc->res_d2, sizeof(double) * sc->nq);
     if (sc->hard_list) pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(sc->nq));
     if (sc->prev_xyz) pcr_dev_free(ctx, sc->prev_xyz, 24 * (size_t)sc->nq);
-    if (sc->open_mask) pcr_dev_free(ctx, sc->open_mask, sizeof(unsigned int) * (size_t)((sc->nq + WT_Q - 1) / WT_Q + 4));
-    if (sc->acc) pcr_dev_free(ctx, sc->acc, sizeof(unsigned long long) * ACC_SETS * PCR_NMOM);
-    sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr; sc->prev_xyz = nullptr; sc->open_mask = nullptr; sc->acc = nullptr;
+    if (sc->items) pcr_dev_free(ctx, sc->items, 32 * (size_t)PASS_GROUPS * pass_item_cap(sc->nq));
+    if (sc->acc) pcr_dev_free(ctx, sc->acc, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS));
+    sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr; sc->prev_xyz = nullptr; sc->items = nullptr; sc->acc = nullptr;
 }
 
 // Enqueues the search stages on `stream` over the `nq` records at `q` (a whole Morton-sorted cloud or a run of it);
 // leaves res_pos (and res_d2 when the scratch has it) on the device.  `st` != null: device-resident ICP loop.
+static unsigned int wtile_point_cap(const pcr_ctx* ctx, int64_t nq) {
+    static const int wt_rounds_env = getenv("PCR_WT_ROUNDS") ? atoi(getenv("PCR_WT_ROUNDS")) : 0;
+    const int nblocks = (int)((nq + 63) / 64);
+    return (unsigned int)WT_PR * (wt_rounds_env > 0 ? wt_rounds_env : (nblocks > 8 * ctx->cu_count ? WT_ROUNDS_LARGE : WT_ROUNDS_SMALL));
+}
+static int wtile_xcd_remap() {
+    static const int xcd_remap = getenv("PCR_TILE_XCD") ? atoi(getenv("PCR_TILE_XCD")) : 1;
+    return xcd_remap;
+}
+
 static int grid_search_enqueue(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq, hipStream_t stream, const pcr_xform* x, int write_back,
-                               double max_d2, bool gated, bool mark, grid_scratch* sc, const pcr_icp_dev_state* st, bool use_prev = false,
-                               const hard_acc_args* acc = nullptr) {
+                               double max_d2, bool gated, bool mark, grid_scratch* sc, const pcr_icp_dev_state* st, bool use_prev = false) {
     const int nblocks = (int)((nq + 63) / 64);
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
     if (mark) pcr_prof_mark(ctx, 0);
-    static const int xcd_remap = getenv("PCR_TILE_XCD") ? atoi(getenv("PCR_TILE_XCD")) : 1;
     {
-        static const int wt_rounds_env = getenv("PCR_WT_ROUNDS") ? atoi(getenv("PCR_WT_ROUNDS")) : 0;
-        const unsigned int wpcap = (unsigned int)WT_PR * (wt_rounds_env > 0 ? wt_rounds_env : (nblocks > 8 * ctx->cu_count ? WT_ROUNDS_LARGE : WT_ROUNDS_SMALL));
         if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)nblocks), stream);
         const int wblocks = (int)((nq + 4 * WT_Q - 1) / (4 * WT_Q));
         hipLaunchKernelGGL(grid_wtile_kernel, dim3(wblocks), dim3(256), 0, stream, (const pcr_grid_view*)idx->d_view, q, (long long)nq, x ? *x : xi, (x || st) ? 1 : 0,
-                           write_back, max_d2, gated ? 1 : 0, xcd_remap, wpcap, sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count, ctx->d_debug, st,
-                           (const wt_xyz*)(use_prev ? sc->prev_xyz : nullptr), acc ? sc->open_mask : nullptr);
+                           write_back, max_d2, gated ? 1 : 0, wtile_xcd_remap(), wtile_point_cap(ctx, nq), sc->res_pos, sc->res_d2, sc->hard_list, sc->hard_count,
+                           ctx->d_debug, st, (const wt_xyz*)(use_prev ? sc->prev_xyz : nullptr));
     }
     if (mark) pcr_prof_mark(ctx, 1);
     // a fixed grid of waves walks the hard list (its length is only known on the device)
     const long long want = (nq + 3) / 4;
     // 8 blocks of 4 waves per CU: twice what is resident at 4 waves per SIMD (4 x CU measured the same, 2 x CU 30 % slower)
     const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
-    hipLaunchKernelGGL(grid_hard_kernel, dim3(g3 + (acc ? acc->acc_blocks : 0)), dim3(256), 0, stream, idx->view, (const work_item*)sc->hard_list,
-                       (const unsigned int*)sc->hard_count, (long long)nq, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug, st,
-                       acc ? *acc : hard_acc_args{});
+    hipLaunchKernelGGL(grid_hard_kernel, dim3(g3), dim3(256), 0, stream, idx->view, (const work_item*)sc->hard_list,
+                       (const unsigned int*)sc->hard_count, (long long)nq, max_d2, gated ? 1 : 0, sc->res_pos, sc->res_d2, ctx->d_debug, st);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
@@ -1374,19 +1670,16 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     const int64_t nq = qc->n;
     grid_scratch sc;
     if ((rc = grid_scratch_alloc(ctx, nq, false, ctx->d_counters + PCR_HARD_COUNTERS, &sc))) return rc;
-    const int n_wtiles = (int)((nq + WT_Q - 1) / WT_Q);
-    if ((rc = pcr_dev_alloc(ctx, 24 * (size_t)nq, &sc.prev_xyz)) ||
-        (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (size_t)(n_wtiles + 4), (void**)&sc.open_mask)) ||
-        (rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * ACC_SETS * PCR_NMOM, (void**)&sc.acc))) {
+    if ((rc = pcr_dev_alloc(ctx, 24 * (size_t)nq, &sc.prev_xyz))) {
         grid_scratch_free(ctx, &sc);
         return rc;
     }
     int grid = (int)((nq + 1023) / 1024);  // four queries per thread
     if (grid > ctx->cu_count) grid = ctx->cu_count;
-    // Fused hard stage + accumulation (fixed-point accumulators): needs a gate (it bounds |a'| by the target's extent) and
-    // enough fraction bits.  Every moment is bounded by M = N * max(R^2, gate, 1), R = half diagonal of the target box + gate radius.
-    hard_acc_args acc_args{};
-    bool fused = gated && getenv("PCR_ICP_NO_FUSED") == nullptr;
+    // One-kernel pass (fixed-point accumulators): needs a gate (it bounds |a'| by the target's extent) and enough fraction
+    // bits.  Every moment is bounded by M = N * max(R^2, gate, 1), R = half diagonal of the target box + gate radius.
+    pass_args pa{};
+    bool fused = gated && nq <= PASS_MAX_NQ && getenv("PCR_ICP_NO_FUSED") == nullptr;
     if (fused) {
         double r2 = 0.0;
         for (int k = 0; k < 3; ++k) r2 += 0.25 * (idx->hi[k] - idx->lo[k]) * (idx->hi[k] - idx->lo[k]);
@@ -1397,14 +1690,18 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         const int F = 61 - ex;
         if (!(M > 0) || !std::isfinite(M) || F < 20) fused = false;   // absurd extents: keep the binary64 slabs
         else {
-            acc_args.acc_blocks = grid;
-            acc_args.q = qc->d;
-            acc_args.open_mask = sc.open_mask;
-            acc_args.acc = sc.acc;
-            acc_args.ticket = ctx->d_counters + 256;   // root ticket + 32 group tickets, 64 bytes apart (words 256..783)
-            acc_args.prev_xyz = (wt_xyz*)sc.prev_xyz;
-            acc_args.scale = ldexp(1.0, F);
-            acc_args.inv_scale = ldexp(1.0, -F);
+            pa.cap = pass_item_cap(nq);
+            if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS), (void**)&sc.acc)) ||
+                (rc = pcr_dev_alloc(ctx, 32 * (size_t)PASS_GROUPS * pa.cap, (void**)&sc.items))) {
+                grid_scratch_free(ctx, &sc);
+                return rc;
+            }
+            pa.items = sc.items;
+            pa.acc = sc.acc;
+            pa.sync = sc.acc + ACC_SETS * PCR_NMOM;
+            pa.prev_xyz = (wt_xyz*)sc.prev_xyz;
+            pa.scale = ldexp(1.0, F);
+            pa.inv_scale = ldexp(1.0, -F);
         }
     }
     pcr_icp_dev_state* d_st = nullptr;
@@ -1429,9 +1726,10 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     la.compat = params->mode == PCR_ICP_COMPAT_MAIN; la.r_metric = params->r_metric;
     la.r_thres = params->r_thres; la.t_thres = params->t_thres;
     hipError_t e = hipMemcpyAsync(d_st, h_st, sizeof(*h_st), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && fused) e = hipMemsetAsync(sc.acc, 0, sizeof(unsigned long long) * ACC_SETS * PCR_NMOM, ctx->stream);
-    acc_args.st = d_st;
-    acc_args.la = la;
+    if (e == hipSuccess && fused) e = hipMemsetAsync(sc.acc, 0, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS), ctx->stream);
+    if (e == hipSuccess && fused) e = hipMemsetAsync(sc.items, 0xff, 32 * (size_t)PASS_GROUPS * pa.cap, ctx->stream);
+    pa.st = d_st;
+    pa.la = la;
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
     int enq = 0, launches = 0;
@@ -1445,13 +1743,22 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         for (int c = 0; c < chunk && rc == PCR_OK; ++c) {
             // from the second pass on, res_pos holds the previous pass's neighbours (same query order, same target)
             static const bool no_prev = getenv("PCR_NO_PREV") != nullptr;
-            rc = grid_search_enqueue(ctx, idx, qc->d, nq, ctx->stream, nullptr, 1, params->max_d2, gated, ctx->profile, &sc, d_st, enq + c > 0 && !no_prev,
-                                     fused ? &acc_args : nullptr);
-            if (rc) break;
-            pcr_prof_mark(ctx, 2);
-            if (!fused) {
-                // (ungated or absurdly large clouds) binary64 slabs: after the write-back of the tile kernel the cloud already
-                // holds the transformed points
+            const bool use_prev = enq + c > 0 && !no_prev;
+            if (fused) {
+                if (ctx->profile) pcr_prof_mark(ctx, 0);
+                if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)((nq + 63) / 64)), ctx->stream);
+                const int wblocks = (int)((nq + 4 * WT_Q - 1) / (4 * WT_Q));
+                hipLaunchKernelGGL(grid_pass_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, (const pcr_grid_view*)idx->d_view, idx->view, qc->d, (long long)nq,
+                                   params->max_d2, wtile_xcd_remap(), wtile_point_cap(ctx, nq), sc.res_pos, ctx->d_debug, use_prev ? 1 : 0, pa);
+                if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
+                if (ctx->profile) pcr_prof_mark(ctx, 1);
+                pcr_prof_mark(ctx, 2);
+            } else {
+                // (ungated or absurdly large clouds) tile -> hard -> binary64 slabs: after the write-back of the tile kernel the
+                // cloud already holds the transformed points
+                rc = grid_search_enqueue(ctx, idx, qc->d, nq, ctx->stream, nullptr, 1, params->max_d2, gated, ctx->profile, &sc, d_st, use_prev);
+                if (rc) break;
+                pcr_prof_mark(ctx, 2);
                 hipLaunchKernelGGL(grid_accumulate_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (const pcr_pt*)qc->d, (long long)nq, xi,
                                    0, (const unsigned int*)sc.res_pos, params->max_d2, gated ? 1 : 0, ctx->d_partials, ctx->d_counters + 64,
                                    (double*)nullptr, sc.hard_count, d_st, la, (wt_xyz*)sc.prev_xyz);
@@ -1473,6 +1780,7 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     pcr_dev_free(ctx, d_st, sizeof(pcr_icp_dev_state));
     if (rc) return rc;
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
+    if (h_st->status == PCR_E_HIP) { ctx->last_error = "ICP pass: a wave gave up waiting on the work queue"; return PCR_E_HIP; }
     double T_cur[16];
     pcr::T_from_xform(h_st->x, T_cur);
     if (!la.compat && h_st->status == PCR_OK && !h_st->converged && h_st->it == params->max_iter && params->max_iter > 0) {

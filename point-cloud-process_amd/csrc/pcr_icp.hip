@@ -170,7 +170,7 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
             float ms = 0;
             if (ctx->profile) hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3);  // per-pass kernel time only while profiling
             nn_ms += ms;
-            pcr::icp_step(&st, ctx->h_pinned, index->view.origin, la);
+            pcr::icp_step(&st, ctx->h_pinned, index->view.origin, la, st.r_diff, st.t_diff);
         }
         pcr_dev_free(ctx, d_mom, sizeof(double) * PCR_NMOM);
         if (rc) return rc;

@@ -2,6 +2,7 @@
 // loop (last block of grid_accumulate_kernel): compose the transform just applied, Procrustes from the moments,
 // convergence test and bookkeeping -- Registration/main.py:125-154 (COMPAT) / icp_template.py:166-198 (TOTAL).
 #pragma once
+#include <cstddef>
 #include "pcr_internal.h"
 #include "pcr_linalg.h"
 
@@ -27,8 +28,11 @@ __host__ __device__ inline void T_mul4(const double A[16], const double B[16], d
     for (int i = 0; i < 16; ++i) C[i] = r[i];
 }
 
-// `m` = the 20 accumulated moments of the pass that just applied st->x to the source.
-__host__ __device__ inline void icp_step(pcr_icp_dev_state* st, const double* m, const double origin[3], const pcr_icp_loop_args& la) {
+// `m` = the 20 accumulated moments of the pass that just applied st->x to the source.  Only the head of *st (everything
+// before the logs) is touched; the per-iteration logs go to r_log / t_log, so that a caller may work on a copy of the head.
+constexpr size_t ICP_STATE_HEAD_BYTES = offsetof(pcr_icp_dev_state, r_diff);
+__host__ __device__ inline void icp_step(pcr_icp_dev_state* st, const double* m, const double origin[3], const pcr_icp_loop_args& la,
+                                         double* r_log, double* t_log) {
     double T_cur[16];
     T_from_xform(st->x, T_cur);
     T_mul4(T_cur, st->T_total, st->T_total);
@@ -72,8 +76,8 @@ __host__ __device__ inline void icp_step(pcr_icp_dev_state* st, const double* m,
         t_diff = sqrt(s);
     }
     st->first = 0;
-    st->r_diff[it] = r_diff;
-    st->t_diff[it] = t_diff;
+    r_log[it] = r_diff;
+    t_log[it] = t_diff;
     for (int i = 0; i < 9; ++i) { st->R_last[i] = R[i]; st->x.r[i] = R[i]; }
     for (int i = 0; i < 3; ++i) { st->t_last[i] = t[i]; st->x.t[i] = t[i]; }
     const bool converged = (r_diff <= la.r_thres && t_diff <= la.t_thres) && (it + 1 >= la.min_iter);

@@ -9,8 +9,7 @@ namespace pcr {
 // One-sided Jacobi SVD of a 3x3 matrix (row-major): H = U diag(s) V^T.
 // Columns of U for zero singular values are completed to an orthonormal basis.
 // One Jacobi rotation of columns P, Q.  Written for the single device thread that solves the ICP step: binary64
-// divisions and square roots are ~30-instruction dependent sequences there, so the rotation uses one sqrt, one
-// division and one reciprocal sqrt (the textbook zeta / t / c form needs three divisions and three square roots),
+// divisions and square roots are long dependent sequences there, so the rotation uses two reciprocal square roots
 // and the convergence tests compare squares instead of dividing.
 template <int P, int Q>
 __host__ __device__ inline void svd3_rotate(double A[9], double V[9], bool& rotated) {
@@ -20,17 +19,32 @@ __host__ __device__ inline void svd3_rotate(double A[9], double V[9], bool& rota
     if (gamma == 0.0) return;
     const double ab = alpha * beta, g2 = gamma * gamma;
     if (g2 <= 1e-34 * ab) return;           // |gamma| <= 1e-17 sqrt(alpha beta): orthogonal to working precision
-    if (g2 >= 1e-32 * ab) rotated = true;   // |gamma| / sqrt(alpha beta) >= 1e-16: another sweep is needed
-    // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (beta - alpha) / (2 gamma), scaled by |2 gamma|
+    // Rotation that zeroes gamma, from the double angle: cos 2t = |d| / h, sin 2t = g / h with d = beta - alpha, g = 2 |gamma|,
+    // h = sqrt(d^2 + g^2); c^2 = (1 + cos 2t) / 2, s = sin 2t / (2 c).  Two reciprocal square roots and no division (the
+    // textbook zeta / t / c form is three divisions and three square roots; each is a ~12-instruction dependent chain for
+    // the single device lane that solves the ICP step).
     const double d = beta - alpha, g = 2.0 * fabs(gamma);
     const bool pos = (d == 0.0) || ((d > 0.0) == (gamma > 0.0));
-    const double t = (pos ? g : -g) / (fabs(d) + sqrt(d * d + g * g));
+    const double h2 = d * d + g * g;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double c = rsqrt(1.0 + t * t);
+    const double rh = rsqrt(h2);
 #else
-    const double c = 1.0 / sqrt(1.0 + t * t);
+    const double rh = 1.0 / sqrt(h2);
 #endif
-    const double sn = c * t;
+    const double c2 = 0.5 + 0.5 * (fabs(d) * rh);       // in [1/2, 1]
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double rc = rsqrt(c2);
+#else
+    const double rc = 1.0 / sqrt(c2);
+#endif
+    const double c = c2 * rc;
+    const double s_abs = 0.5 * (g * rh) * rc;
+    const double sn = pos ? s_abs : -s_abs;
+    // Another sweep is needed unless what this sweep leaves behind is below working precision.  A rotation by sine s changes
+    // the other two inner products by at most |s| times their size, so after a sweep whose inner products were all below
+    // eps (relative) and whose sines were all below 1e-8 the residue is <= eps * 1e-8: eps < 1e-8 needs no further sweep.
+    // (Close singular values give large angles for tiny gamma: the sine test catches them.)
+    if (g2 >= 1e-16 * ab || (g2 >= 1e-32 * ab && s_abs * s_abs >= 1e-16)) rotated = true;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double ap = A[3 * i + P], aq = A[3 * i + Q];
