@@ -22,6 +22,7 @@
 // append saturates at ~88 appends/us on this chip and cost more than the search).  Pruning only ever skips a cell whose
 // box distance exceeds a bound that is itself >= the final answer, so every stage returns the exact nearest neighbour
 // (lowest index on ties).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -989,6 +990,8 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
 //             waiting waves would keep the slots the missing tiles need.  Until the group has started completely a free
 //             wave therefore only takes items that are already there (compare-and-swap while claimed < reserved) and
 //             leaves otherwise.  Progress: the tile that finishes last drains the queue itself.
+//   variants  inline_queue = 0: the launch only publishes and grid_drain_kernel (below) serves the queues -- the host's choice
+//             while several ICP loops of the process are in flight; same results bit for bit.
 //   finish    vmcnt(0) (own atomics acknowledged), then a two-level ticket (one word per group, then a root).
 #ifndef PCR_ACC_SETS
 #define PCR_ACC_SETS 64
@@ -1039,9 +1042,100 @@ union pass_lds {
     double xch[WT_Q * (PCR_NMOM - 1)];
 };
 
+// one queued query, served by the calling wave: exact search, then its moments (rounded to fixed point once) and its result
+__device__ __forceinline__ static void pass_serve_item(const pcr_grid_view& gv, pass_lds* L, const int lane, const unsigned long long w, const double max_d2,
+                                                       const pass_args& A, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg,
+                                                       const unsigned int dbg_slot, const unsigned long long t_start) {
+    // lanes 0..3 hold the item's four words
+    const unsigned int w_lo = (unsigned int)w, w_hi = (unsigned int)(w >> 32);
+    const double ax = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 0), __builtin_amdgcn_readlane((int)w_lo, 0));
+    const double ay = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 1), __builtin_amdgcn_readlane((int)w_lo, 1));
+    const double az = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 2), __builtin_amdgcn_readlane((int)w_lo, 2));
+    const unsigned int qi = (unsigned int)__builtin_amdgcn_readlane((int)w_lo, 3);
+    const float cand_b2 = __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)w_hi, 3));
+    const unsigned long long h_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned int h_steps = 0, h_pts = 0;
+    int s_level0 = 0;
+    double bd2;
+    long long bid;
+    unsigned int bpos;
+    const bool have_cand = cand_b2 < INFINITY;
+    hard_search(gv, &L->h, lane, ax, ay, az, have_cand ? fmin((double)cand_b2, max_d2) : max_d2, have_cand, bd2, bid, bpos, h_steps, h_pts, s_level0);
+    wave_sync();
+    if (bpos != POS_NONE) {   // wave-uniform: after the merge every lane holds the same result
+        if (lane == 0) {
+            const pcr_pt b = as_global(gv.pts)[bpos];
+            A.prev_xyz[qi] = wt_xyz{b.x, b.y, b.z};
+            double m[PCR_NMOM];
+#pragma unroll
+            for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+            moments_add(m, gv.origin, ax, ay, az, b, max_d2, 1);
+#pragma unroll
+            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xch[k] = m[k];
+        }
+        wave_sync();
+        acc_fixed_add(A.acc, qi, lane, lane < PCR_NMOM - 1 ? L->xch[lane] : 0.0, A.scale);
+        wave_sync();
+    }
+    if (lane == 0) {
+        res_pos[qi] = bpos;
+        if (dbg && dbg_slot < 60000) {
+            dbg[(1 << 17) + dbg_slot * 4 + 0] = __builtin_amdgcn_s_memtime() - h_t0;
+            dbg[(1 << 17) + dbg_slot * 4 + 1] = ((unsigned long long)h_steps << 32) | (unsigned int)((h_t0 - t_start) >> 4);
+            dbg[(1 << 17) + dbg_slot * 4 + 2] = h_pts;
+            dbg[(1 << 17) + dbg_slot * 4 + 3] = (unsigned long long)have_cand | ((unsigned long long)(s_level0 + 1) << 8);
+        }
+    }
+}
+
+// The wave that leaves a pass last: totals of the fixed-point accumulators -> Procrustes step -> convergence test -> loop state.
+// lane l < 60 owns moment l % 20 of every third set: independent loads, integer sums (order irrelevant), words zeroed behind.
+// The head of the loop state travels with them (one 8-byte word per lane) into LDS: the step reads and updates ~50 of its words.
+__device__ __forceinline__ static void pass_finish(const pcr_grid_view& gv, pass_lds* L, const int lane, const pass_args& A, unsigned long long* root,
+                                                   unsigned long long* __restrict__ dbg) {
+    constexpr int HEAD_WORDS = (int)(pcr::ICP_STATE_HEAD_BYTES / 8);
+    static_assert(pcr::ICP_STATE_HEAD_BYTES % 8 == 0 && HEAD_WORDS <= 64, "state head: one word per lane");
+    double* const head = L->xch + 32;   // 16-byte aligned, behind the 20 moments
+    unsigned long long hw = 0;
+    if (lane < HEAD_WORDS) hw = reinterpret_cast<const unsigned long long*>(A.st)[lane];
+    const int mom = lane % PCR_NMOM, part = lane / PCR_NMOM;
+    long long sum = 0;
+    if (part < 3) {
+        constexpr int PER = (ACC_SETS + 2) / 3;
+        unsigned long long v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int set = part + 3 * j;
+            v[j] = set < ACC_SETS ? ld_dev(A.acc + (size_t)set * PCR_NMOM + mom) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int set = part + 3 * j;
+            if (v[j]) st_dev(A.acc + (size_t)set * PCR_NMOM + mom, 0ull);
+            sum += (long long)v[j];
+        }
+    }
+    if (dbg && lane == 0) dbg[(1 << 19) - 4] = __builtin_amdgcn_s_memrealtime();
+    sum += __shfl(sum, lane + PCR_NMOM, 64) + __shfl(sum, lane + 2 * PCR_NMOM, 64);   // lanes 0..19: all three parts
+    wave_sync();
+    if (dbg && lane == 0) dbg[(1 << 19) - 3] = __builtin_amdgcn_s_memrealtime();
+    if (lane < PCR_NMOM) L->xch[lane] = (double)sum * A.inv_scale;
+    if (lane < HEAD_WORDS) reinterpret_cast<unsigned long long*>(head)[lane] = hw;
+    wave_sync();
+    if (lane == 0) {
+        pcr_icp_dev_state* hs = reinterpret_cast<pcr_icp_dev_state*>(head);
+        if (ld_dev(root + 16)) { hs->status = PCR_E_HIP; hs->stop = 1; st_dev(root + 16, 0ull); }
+        else pcr::icp_step(hs, L->xch, gv.origin, A.la, A.st->r_diff, A.st->t_diff);
+    }
+    wave_sync();
+    if (dbg && lane == 0) dbg[(1 << 19) - 2] = __builtin_amdgcn_s_memrealtime();
+    if (lane < HEAD_WORDS) reinterpret_cast<unsigned long long*>(A.st)[lane] = reinterpret_cast<const unsigned long long*>(head)[lane];
+    if (dbg && lane == 0) dbg[(1 << 19) - 1] = __builtin_amdgcn_s_memrealtime();
+}
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
 grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, double max_d2, int xcd_remap,
-                 unsigned int pcap, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg, int use_prev, pass_args A) {
+                 unsigned int pcap, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg, int use_prev, int inline_queue, pass_args A) {
     __shared__ pass_lds s_lds[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned int tile = wtile_block(xcd_remap) * 4 + wave;
@@ -1077,7 +1171,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     const bool nb_known = proven && S.won == P.seed_pos;   // same neighbour as in the last pass: its coordinates came with the seed
     if (proven && !nb_known) nb = as_global(gv.pts)[S.won];
     bool all_started = false;
-    {
+    if (inline_queue) {
         unsigned long long sv = 0;
         if (lane == 0) sv = ld_dev(g_started);
         all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)sv) == g_tiles;
@@ -1105,7 +1199,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
             st_dev(it + 3, (unsigned long long)(unsigned int)S.qi | ((unsigned long long)__float_as_uint(cand ? S.bound2 : INFINITY) << 32));
         }
         const unsigned int R = base + (unsigned int)__popcll(um);
-        if (done_before == g_tiles - 1u) {
+        if (done_before == g_tiles - 1u && inline_queue) {
             // last tile of the group: no slot beyond R will ever be filled; whoever holds one reads this and leaves
             for (unsigned int k = lane; k < g_tiles; k += 64) st_dev(items + (size_t)(R + k) * 4 + 3, ITEM_POISON);
             group_done = true;
@@ -1146,6 +1240,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         atomicMax(&dbg[blockIdx.x * 4 + 0], __builtin_amdgcn_s_memtime() - t_start);
     }
     if (dbg) rt_acc = __builtin_amdgcn_s_memrealtime();
+    if (!inline_queue) return;   // throughput variant: grid_drain_kernel serves the queues and finishes
     // ---- serve the group's queue
     bool failed = false;
     while (!group_done) {
@@ -1197,48 +1292,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         if (lane < 4 && w != ITEM_NONE) st_dev(it + lane, ITEM_NONE);   // the slot is clean for the next launch
         if (poisoned) break;
         ++n_items;
-        const unsigned int w_lo = (unsigned int)w, w_hi = (unsigned int)(w >> 32);
-        const double ax = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 0), __builtin_amdgcn_readlane((int)w_lo, 0));
-        const double ay = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 1), __builtin_amdgcn_readlane((int)w_lo, 1));
-        const double az = __hiloint2double(__builtin_amdgcn_readlane((int)w_hi, 2), __builtin_amdgcn_readlane((int)w_lo, 2));
-        const unsigned int qi = (unsigned int)__builtin_amdgcn_readlane((int)w_lo, 3);
-        const float cand_b2 = __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)w_hi, 3));
-        const unsigned long long h_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
-        unsigned int h_steps = 0, h_pts = 0;
-        int s_level0 = 0;
-        double bd2;
-        long long bid;
-        unsigned int bpos;
-        const bool have_cand = cand_b2 < INFINITY;
-        hard_search(gv, &L->h, lane, ax, ay, az, have_cand ? fmin((double)cand_b2, max_d2) : max_d2, have_cand, bd2, bid, bpos, h_steps, h_pts, s_level0);
-        wave_sync();
-        if (bpos != POS_NONE) {   // wave-uniform: after the merge every lane holds the same result
-            if (lane == 0) {
-                const pcr_pt b = as_global(gv.pts)[bpos];
-                A.prev_xyz[qi] = wt_xyz{b.x, b.y, b.z};
-                double m[PCR_NMOM];
-#pragma unroll
-                for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
-                moments_add(m, gv.origin, ax, ay, az, b, max_d2, 1);
-#pragma unroll
-                for (int k = 0; k < PCR_NMOM - 1; ++k) L->xch[k] = m[k];
-            }
-            wave_sync();
-            acc_fixed_add(A.acc, qi, lane, lane < PCR_NMOM - 1 ? L->xch[lane] : 0.0, A.scale);
-            wave_sync();
-        }
-        if (lane == 0) {
-            res_pos[qi] = bpos;
-            if (dbg) {
-                const unsigned int w_i = g + PASS_GROUPS * mine;
-                if (w_i < 60000) {
-                    dbg[(1 << 17) + w_i * 4 + 0] = __builtin_amdgcn_s_memtime() - h_t0;
-                    dbg[(1 << 17) + w_i * 4 + 1] = ((unsigned long long)h_steps << 32) | (unsigned int)((h_t0 - t_start) >> 4);
-                    dbg[(1 << 17) + w_i * 4 + 2] = h_pts;
-                    dbg[(1 << 17) + w_i * 4 + 3] = (unsigned long long)have_cand | ((unsigned long long)(s_level0 + 1) << 8);
-                }
-            }
-        }
+        pass_serve_item(gv, L, lane, w, max_d2, A, res_pos, dbg, g + PASS_GROUPS * mine, t_start);
     }
     const unsigned long long rt_loop = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     // ---- the wave that leaves last converts the totals, solves the Procrustes step and tests convergence
@@ -1276,49 +1330,64 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         d[0] = rt_start; d[1] = rt_tile; d[2] = rt_acc; d[3] = rt_loop; d[4] = n_items; d[5] = n_polls | ((unsigned long long)n_casfail << 32); d[6] = S.dbg_pairs | ((unsigned long long)S.dbg_passes << 40) | ((unsigned long long)__popcll(um) << 48); d[7] = __builtin_amdgcn_s_memrealtime();
     }
     if (!__builtin_amdgcn_readfirstlane(last)) return;
-    // lane l < 60 owns moment l % 20 of every third set: independent loads, integer sums (order irrelevant), words zeroed behind.
-    // The head of the loop state travels with them (one 8-byte word per lane) into LDS: the Procrustes step reads and updates ~50
-    // of its words, and one lane going to global memory for them was a chain of dependent round trips (6.7 us for this block).
-    {
-        constexpr int HEAD_WORDS = (int)(pcr::ICP_STATE_HEAD_BYTES / 8);
-        static_assert(pcr::ICP_STATE_HEAD_BYTES % 8 == 0 && HEAD_WORDS <= 64, "state head: one word per lane");
-        double* const head = L->xch + 32;   // 16-byte aligned, behind the 20 moments
-        unsigned long long hw = 0;
-        if (lane < HEAD_WORDS) hw = reinterpret_cast<const unsigned long long*>(A.st)[lane];
-        const int mom = lane % PCR_NMOM, part = lane / PCR_NMOM;
-        long long sum = 0;
-        if (part < 3) {
-            constexpr int PER = (ACC_SETS + 2) / 3;
-            unsigned long long v[PER];
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const int set = part + 3 * j;
-                v[j] = set < ACC_SETS ? ld_dev(A.acc + (size_t)set * PCR_NMOM + mom) : 0ull;
-            }
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const int set = part + 3 * j;
-                if (v[j]) st_dev(A.acc + (size_t)set * PCR_NMOM + mom, 0ull);
-                sum += (long long)v[j];
-            }
+    pass_finish(gv, L, lane, A, root, dbg);
+}
+
+// Throughput variant of the pass, used while several ICP loops of the process are in flight: waves that wait for work buy
+// latency for one pair with slots the other pairs' kernels could use (4 pairs in flight: 1.5e9 correspondences/s against
+// 3.1e9), and without waiting the last tile of a group would serve what is left of its queue alone (430 us).  So the tile
+// kernel only publishes (publish_only), and this second launch serves the queues with a static partition -- all counts are
+// final at the kernel boundary -- and finishes.  What a wave adds to the accumulators (one rounding per tile, one per item)
+// never depends on who serves an item or when: both variants give the same result bit for bit.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
+grid_drain_kernel(pcr_grid_view gv, double max_d2, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg, pass_args A) {
+    __shared__ pass_lds s_lds[4];
+    if (A.st->stop) return;
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    pass_lds* L = &s_lds[wave];
+    // exclusive prefix of the groups' item counts (lanes 0..PASS_GROUPS-1 hold one group each; written by the previous launch)
+    static_assert(PASS_GROUPS <= 64, "one group per lane");
+    const unsigned int l_cnt = lane < PASS_GROUPS ? (unsigned int)(A.sync[(size_t)PASS_SYNC_STRIDE * lane] & Q_MASK) : 0u;
+    unsigned int total = 0;
+    const unsigned int l_exc = wave_excl_scan_u32(l_cnt, lane, &total);
+    const unsigned int n_waves = gridDim.x * 4;
+    for (unsigned int w_i = blockIdx.x * 4 + wave; w_i < total; w_i += n_waves) {
+        const int grp = (int)__ffsll((long long)__ballot(lane < PASS_GROUPS && l_exc <= w_i && w_i < l_exc + l_cnt)) - 1;   // exactly one group holds item w_i
+        const unsigned int idx = w_i - (unsigned int)__builtin_amdgcn_readlane((int)l_exc, grp);
+        unsigned long long* it = A.items + ((size_t)grp * A.cap + idx) * 4;
+        unsigned long long w = ITEM_NONE;
+        if (lane < 4) {
+            w = it[lane];
+            it[lane] = ITEM_NONE;   // the slot is clean for the next pass
         }
-        if (dbg && lane == 0) dbg[(1 << 19) - 4] = __builtin_amdgcn_s_memrealtime();
-        sum += __shfl(sum, lane + PCR_NMOM, 64) + __shfl(sum, lane + 2 * PCR_NMOM, 64);   // lanes 0..19: all three parts
-        wave_sync();
-        if (dbg && lane == 0) dbg[(1 << 19) - 3] = __builtin_amdgcn_s_memrealtime();
-        if (lane < PCR_NMOM) L->xch[lane] = (double)sum * A.inv_scale;
-        if (lane < HEAD_WORDS) reinterpret_cast<unsigned long long*>(head)[lane] = hw;
-        wave_sync();
-        if (lane == 0) {
-            pcr_icp_dev_state* hs = reinterpret_cast<pcr_icp_dev_state*>(head);
-            if (ld_dev(root + 16)) { hs->status = PCR_E_HIP; hs->stop = 1; st_dev(root + 16, 0ull); }
-            else pcr::icp_step(hs, L->xch, gv.origin, A.la, A.st->r_diff, A.st->t_diff);
-        }
-        wave_sync();
-        if (dbg && lane == 0) dbg[(1 << 19) - 2] = __builtin_amdgcn_s_memrealtime();
-        if (lane < HEAD_WORDS) reinterpret_cast<unsigned long long*>(A.st)[lane] = reinterpret_cast<const unsigned long long*>(head)[lane];
-        if (dbg && lane == 0) dbg[(1 << 19) - 1] = __builtin_amdgcn_s_memrealtime();
+        pass_serve_item(gv, L, lane, w, max_d2, A, res_pos, dbg, w_i, t_start);
     }
+    // ---- two-level ticket over the blocks' waves (group = wave index % PASS_GROUPS), then the finish
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* const root = A.sync + (size_t)PASS_SYNC_STRIDE * PASS_GROUPS;
+    const unsigned int wid = blockIdx.x * 4 + wave;
+    const unsigned int n_groups = n_waves < (unsigned int)PASS_GROUPS ? n_waves : (unsigned int)PASS_GROUPS;
+    const unsigned int g = wid % n_groups;
+    const unsigned int g_size = n_waves / n_groups + (g < n_waves % n_groups ? 1u : 0u);
+    unsigned long long* const g_ticket = A.sync + (size_t)PASS_SYNC_STRIDE * g + 17;
+    int last = 0;
+    if (lane == 0) {
+        if (__hip_atomic_fetch_add(g_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(g_size - 1u)) {
+            st_dev(g_ticket, 0ull);
+            if (__hip_atomic_fetch_add(root, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n_groups - 1u)) {
+                st_dev(root, 0ull);
+                last = 1;
+            }
+        }
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+    // queue words of the tile kernel: clean for the next pass (every wave of this launch has read them: it took its ticket after)
+    if (lane < PASS_GROUPS) {
+        st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane, 0ull);
+        st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 16, 0ull);
+    }
+    pass_finish(gv, L, lane, A, root, dbg);
 }
 
 // --------------------------------------------------------------- epilogues
@@ -1662,8 +1731,19 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
 // order, solves the 3x3 Procrustes step, tests convergence and writes the next increment into the device state, which
 // the next tile kernel reads.  The host enqueues a CHUNK of passes, then copies the 4.5-KB state back once; passes
 // enqueued behind a stop return at their first instruction.
+// ICP loops of this process in flight on the device (any context)
+static std::atomic<int> g_loops_in_flight{0};
+struct loop_guard {
+    int n;
+    loop_guard() : n(g_loops_in_flight.fetch_add(1) + 1) {}
+    ~loop_guard() { g_loops_in_flight.fetch_sub(1); }
+};
+
 int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_icp_params* params, const double T0[16],
                       pcr_icp_result* res) {
+    const loop_guard in_flight;
+    const char* const wait_s = getenv("PCR_PASS_INLINE");   // read per call: the tests switch it
+    const int wait_env = wait_s ? atoi(wait_s) : -1;   // 0 / 1 force a variant; default: inline when alone on the device
     const bool gated = (params->max_d2 > 0) && std::isfinite(params->max_d2);
     int rc = pcr_cloud_morton_sort(ctx, qc, idx->cell);
     if (rc) return rc;
@@ -1744,14 +1824,21 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             // from the second pass on, res_pos holds the previous pass's neighbours (same query order, same target)
             static const bool no_prev = getenv("PCR_NO_PREV") != nullptr;
             const bool use_prev = enq + c > 0 && !no_prev;
+            const int inline_queue = wait_env >= 0 ? wait_env : (g_loops_in_flight.load(std::memory_order_relaxed) == 1 ? 1 : 0);
             if (fused) {
                 if (ctx->profile) pcr_prof_mark(ctx, 0);
                 if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)((nq + 63) / 64)), ctx->stream);
                 const int wblocks = (int)((nq + 4 * WT_Q - 1) / (4 * WT_Q));
                 hipLaunchKernelGGL(grid_pass_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, (const pcr_grid_view*)idx->d_view, idx->view, qc->d, (long long)nq,
-                                   params->max_d2, wtile_xcd_remap(), wtile_point_cap(ctx, nq), sc.res_pos, ctx->d_debug, use_prev ? 1 : 0, pa);
-                if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
+                                   params->max_d2, wtile_xcd_remap(), wtile_point_cap(ctx, nq), sc.res_pos, ctx->d_debug, use_prev ? 1 : 0, inline_queue, pa);
                 if (ctx->profile) pcr_prof_mark(ctx, 1);
+                if (!inline_queue) {
+                    // 8 blocks of 4 waves per CU, like the stand-alone hard stage
+                    const long long want = (nq + 3) / 4;
+                    const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
+                    hipLaunchKernelGGL(grid_drain_kernel, dim3(g3), dim3(256), 0, ctx->stream, idx->view, params->max_d2, sc.res_pos, ctx->d_debug, pa);
+                }
+                if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
                 pcr_prof_mark(ctx, 2);
             } else {
                 // (ungated or absurdly large clouds) tile -> hard -> binary64 slabs: after the write-back of the tile kernel the

@@ -249,6 +249,18 @@ def test_icp_is_bitwise_reproducible(pcp, syn):
         outs.append((r["T_total"].tobytes(), r["n_assoc"], sd.download().tobytes()))
         sd.free()
     assert all(o == outs[0] for o in outs[1:])
+    # the two variants of the pass (one launch with the work queue served in place / publish, then a second launch that
+    # serves it: what the library picks while several loops are in flight) round the same partial sums: same bits
+    import os
+    try:
+        for v in ("1", "0"):
+            os.environ["PCR_PASS_INLINE"] = v
+            sd = pcp.DeviceCloud.upload(src)
+            r = pcp.icp_device(sd, index, np.eye(4), mode="total", max_iter=30, r_thres=-1.0, t_thres=-1.0, min_iter=30)
+            assert (r["T_total"].tobytes(), r["n_assoc"], sd.download().tobytes()) == outs[0], v
+            sd.free()
+    finally:
+        os.environ.pop("PCR_PASS_INLINE", None)
     idx0 = index.nn1(src)
     idx1 = index.nn1(src)
     assert np.array_equal(idx0[0], idx1[0]) and np.array_equal(idx0[1], idx1[1])
