@@ -572,7 +572,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                         }
                         res_d2[qi] = dd;
                     }
-                    if (bpos != seed_pos) res_pos[qi] = bpos;   // (seeded passes: most neighbours do not change)
+                    if (!prev_xyz || bpos != seed_pos) res_pos[qi] = bpos;   // (seeded passes: most neighbours do not change)
                 }
             } else {
                 WT_WHY(ambiguous ? 3 : 4);
@@ -965,8 +965,9 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
 //
 // Moments meet in 64-bit FIXED-POINT accumulators (value * 2^F, F chosen on the host so that N * R^2 * 2^F < 2^61):
 // integer additions commute, so waves may add in any order -- device-scope atomics, no slabs -- and the totals are still
-// bitwise reproducible.  Each wave total / hard item is rounded to 2^-F once (<= (waves + items) * 2^-F on a sum bounded
-// by N R^2: ~1e-14 relative, two orders above binary64 round-off and five below the parity bar).  64 sets of 20 words:
+// bitwise reproducible.  Every correspondence is rounded to 2^-F once, on its own (<= N * 2^-F / 2 on a sum bounded by N R^2:
+// < 1e-12 relative at 120 000 points, three orders below the parity bar), so the totals are also independent of how the
+// queries are grouped into tiles and queue items.  64 sets of 20 words:
 // 1024 sets made the finishing read 14 us slower, one set serialises the atomics at their L2 channel.
 //
 // Everything waves tell each other INSIDE the launch goes through device-scope atomics (performed at the coherence
@@ -1029,6 +1030,10 @@ __device__ static inline void acc_fixed_add(unsigned long long* __restrict__ acc
         atomicAdd(acc + (size_t)(set % ACC_SETS) * PCR_NMOM + lane, (unsigned long long)__double2ll_rn(mk * scale));   // two's complement
 }
 
+__device__ static inline void acc_fixed_add_ll(unsigned long long* __restrict__ acc, unsigned int set, int lane, long long v) {
+    if (lane < PCR_NMOM - 1 && v != 0) atomicAdd(acc + (size_t)(set % ACC_SETS) * PCR_NMOM + lane, (unsigned long long)v);
+}
+
 __device__ static inline unsigned long long ld_dev(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1040,6 +1045,7 @@ union pass_lds {
     wtile_lds t;
     hard_lds h;
     double xch[WT_Q * (PCR_NMOM - 1)];
+    long long xll[WT_Q * (PCR_NMOM - 1)];
 };
 
 // one queued query, served by the calling wave: exact search, then its moments (rounded to fixed point once) and its result
@@ -1210,7 +1216,9 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         }
         group_done = group_done && have_claim && mine >= R;   // ... and every slot below R already has its wave: nothing left for this one
     }
-    // ---- moments of the proven queries: 19 moments per query through the wave's LDS slice, lanes 0..18 add them in query order
+    // ---- moments of the proven queries.  Every correspondence is rounded to the fixed-point grid ONCE, by itself; from there on
+    // only integers are added (here through the wave's LDS slice, then by the atomics): the totals do not depend on how queries
+    // are grouped into tiles or queue items, or on any order.
     {
         double m[PCR_NMOM];
 #pragma unroll
@@ -1222,22 +1230,16 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         }
         if (lane < WT_Q) {
 #pragma unroll
-            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xch[lane * (PCR_NMOM - 1) + k] = m[k];
+            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xll[lane * (PCR_NMOM - 1) + k] = __double2ll_rn(m[k] * A.scale);
         }
         wave_sync();
-        double tot = 0.0;
+        long long tot = 0;
         if (lane < PCR_NMOM - 1) {
 #pragma unroll 8
-            for (int j = 0; j < WT_Q; ++j) tot += L->xch[j * (PCR_NMOM - 1) + lane];
+            for (int j = 0; j < WT_Q; ++j) tot += L->xll[j * (PCR_NMOM - 1) + lane];
         }
-        acc_fixed_add(A.acc, tile, lane, tot, A.scale);
+        acc_fixed_add_ll(A.acc, tile, lane, tot);
         wave_sync();
-    }
-    if (dbg && lane == 0) {
-        atomicAdd(&dbg[blockIdx.x * 4 + 1], S.dbg_pairs);
-        atomicAdd(&dbg[blockIdx.x * 4 + 2], (unsigned long long)S.dbg_passes);
-        atomicAdd(&dbg[blockIdx.x * 4 + 3], (unsigned long long)__popcll(um));
-        atomicMax(&dbg[blockIdx.x * 4 + 0], __builtin_amdgcn_s_memtime() - t_start);
     }
     if (dbg) rt_acc = __builtin_amdgcn_s_memrealtime();
     if (!inline_queue) return;   // throughput variant: grid_drain_kernel serves the queues and finishes

@@ -51,3 +51,6 @@ if ph.sum() > 0:   # -DPCR_WT_DIAG build: phase cycles of wave 0 of every block 
     for i, nm in enumerate(names[:7]):
         print("   %-14s %8.0f %8.0f %8.0f" % (nm, np.median(ph[:, i]), np.percentile(ph[:, i], 90), ph[:, i].max()))
     print("   total median %.0f" % np.median(ph.sum(axis=1)))
+    tot = ph.sum(axis=1)
+    heavy = tot >= np.percentile(tot, 97)
+    print("the heaviest 3 %% of these waves (%d): mean cycles per phase" % heavy.sum(), {nm: int(ph[heavy, i].mean()) for i, nm in enumerate(names[:7])}, "total", int(tot[heavy].mean()))
