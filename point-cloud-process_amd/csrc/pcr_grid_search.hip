@@ -119,8 +119,14 @@ constexpr int WT_PASSES = PCR_WT_PASSES;
 constexpr int WT_PASSES_SEEDED = WT_PASSES < PCR_WT_PASSES_SEEDED ? WT_PASSES : PCR_WT_PASSES_SEEDED;
 constexpr int WT_ROUNDS_SMALL = 768 / WT_PR, WT_ROUNDS_LARGE = 2304 / WT_PR;   // staged-point caps of 768 / 2304 per tile
 
+#ifndef PCR_WT_MFMA
+#define PCR_WT_MFMA 1   // filter on the matrix cores (v_mfma_f32_32x32x2_f32); 0 = packed binary32 VALU filter
+#endif
 struct wtile_lds {
     alignas(16) float px[WT_PR + 8], py[WT_PR + 8], pz[WT_PR + 8];
+#if PCR_WT_MFMA
+    alignas(16) float pn[WT_PR + 8];   // |p|^2 of the staged point (binary32, from the rounded local coordinates)
+#endif
     unsigned int ppos[WT_PR];
     unsigned int c_start[WT_MAXC];
     unsigned int c_off[WT_MAXC + 1];
@@ -439,6 +445,12 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
         const float qxf = (float)(ax - ox), qyf = (float)(ay - oy), qzf = (float)(az - oz);
         float fm = INFINITY, fs = INFINITY, s_in = INFINITY;
         unsigned int bpos = POS_NONE;
+#if PCR_WT_MFMA
+        static_assert(WT_Q == 32, "the matrix-core filter maps the 32 queries of a tile to the 32 columns of a tile product");
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        const float mf_b1 = lane < 32 ? -2.0f * qxf : -2.0f * qyf, mf_b2 = lane < 32 ? -2.0f * qzf : 1.0f;
+        float bd = INFINITY;   // direct-form squared distance of this lane's best point so far
+#endif
         if (total > 0) {
             const f2 qx2 = {qxf, qxf}, qy2 = {qyf, qyf}, qz2 = {qzf, qzf};
             const int slice = lane / WT_Q;
@@ -477,13 +489,85 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                 for (int c3 = 0; c3 < WT_CH; ++c3) {
                     const unsigned int k = 64 * c3 + lane;
                     if (k < cnt) {
-                        L->px[k] = (float)(rec[c3].x - ox); L->py[k] = (float)(rec[c3].y - oy); L->pz[k] = (float)(rec[c3].z - oz);
+                        const float fx = (float)(rec[c3].x - ox), fy = (float)(rec[c3].y - oy), fz = (float)(rec[c3].z - oz);
+                        L->px[k] = fx; L->py[k] = fy; L->pz[k] = fz;
+#if PCR_WT_MFMA
+                        L->pn[k] = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+#endif
                         L->ppos[k] = jj[c3];
                     }
                 }
+#if PCR_WT_MFMA
+                // pad the last block of 32 with points nobody can win (finite: no inf - inf in the expanded form)
+                if (lane < 32 && cnt + lane < ((cnt + 31u) & ~31u)) { L->px[cnt + lane] = 1e15f; L->py[cnt + lane] = 0.0f; L->pz[cnt + lane] = 0.0f; L->pn[cnt + lane] = 1e30f; }
+#else
                 if (lane < 8) { L->px[cnt + lane] = 1e30f; L->py[cnt + lane] = 0.0f; L->pz[cnt + lane] = 0.0f; }  // pad the last group of 8
+#endif
                 wave_sync();
                 WT_STAMP(4);
+#if PCR_WT_MFMA
+                // Filter on the matrix cores.  Expanded form |p|^2 - 2 q.p (the query's own |q|^2 is added at the end): one 32 x 32
+                // tile = 32 staged points (rows) x the 32 queries (columns), K = 4 = two v_mfma_f32_32x32x2_f32:
+                //   A rows (px, py | pz, |p|^2): lane l supplies point l % 32, k = l / 32 -- two 4-byte LDS reads per lane and block
+                //   B cols (-2qx, -2qy | -2qz, 1): two registers per lane for the whole pass
+                //   C: lane l holds query l % 32 against the 16 points 8 g + 4 (l / 32) + e of the block (g, e = 0..3)
+                // so the two lanes of a query see half a block each -- the two candidate slices of the packed-VALU filter it replaces,
+                // which read 96 bytes of LDS per lane for every 8 points and kept the VALU busy with 35 instructions for them (the
+                // filter was half of a heavy tile's lifetime, bound by LDS return bandwidth and VALU issue of the whole CU).
+                // The tile values only ORDER blocks: the winner inside the best block is found by the direct form below, and every
+                // other block enters the proof through its minimum minus the bound d_arith on the expanded form's rounding error.
+                {
+                    int rk = -1;
+                    const unsigned int nblk = (cnt + 31u) >> 5;
+                    const float* const arow1 = lane < 32 ? L->px : L->py;
+                    const float* const arow2 = lane < 32 ? L->pz : L->pn;
+#pragma unroll 1
+                    for (unsigned int blk = 0; blk < nblk; ++blk) {
+                        const float a1 = arow1[32 * blk + (lane & 31)], a2 = arow2[32 * blk + (lane & 31)];
+                        f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, mf_b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, mf_b2, acc, 0, 0, 0);
+                        float m = fmin3(acc[0], acc[1], acc[2]);
+                        m = fmin3(m, acc[3], acc[4]);
+                        m = fmin3(m, acc[5], acc[6]);
+                        m = fmin3(m, acc[7], acc[8]);
+                        m = fmin3(m, acc[9], acc[10]);
+                        m = fmin3(m, acc[11], acc[12]);
+                        m = fmin3(m, acc[13], acc[14]);
+                        m = fminf(m, acc[15]);
+                        const bool lt = part && m < fm;
+                        if (part) {
+                            fs = __builtin_amdgcn_fmed3f(m, fm, fs);
+                            fm = __builtin_amdgcn_fmed3f(m, fm, -INFINITY);
+                        }
+                        rk = lt ? (int)blk : rk;
+                    }
+                    if (rk >= 0) {
+                        // the 16 points this lane saw in its best block, by the direct form
+                        float best = INFINITY, second = INFINITY;
+                        int bi = 0;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int k = 32 * rk + 8 * g + 4 * (lane >> 5);
+                            const f4 bx4 = *reinterpret_cast<const f4*>(&L->px[k]);
+                            const f4 by4 = *reinterpret_cast<const f4*>(&L->py[k]);
+                            const f4 bz4 = *reinterpret_cast<const f4*>(&L->pz[k]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float ddx = qxf - bx4[e], ddy = qyf - by4[e], ddz = qzf - bz4[e];
+                                const float dj = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx));
+                                if (dj < best) { second = best; best = dj; bi = k + e; }
+                                else if (dj < second) second = dj;
+                            }
+                        }
+                        if (best < bd) {
+                            s_in = fminf(s_in, fminf(bd, second));
+                            bd = best;
+                            bpos = L->ppos[bi];
+                        } else s_in = fminf(s_in, best);
+                    }
+                }
+#else
                 // filter: slice s takes groups s, s+4, ... of 8 staged points (see grid_tile_kernel for the arithmetic)
                 if (part) {
                     int rk = -1;
@@ -529,10 +613,25 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                         s_in = second;
                     }
                 }
+#endif
                 wave_sync();
                 WT_STAMP(5);
             }
+#if PCR_WT_MFMA
+            {
+                // from here on fm = the winner's direct-form value, fs = a lower bound of every other staged point's value: the blocks'
+                // minima come from the expanded form in binary32 -- |q|^2, |p|^2 (3 roundings each), 4 multiply-adds (counted as 8
+                // roundings, in case they are not fused), 1 addition, all on magnitudes <= (|q| + |p|)^2 <= 12 R^2 -- within
+                // 126 u R^2 of the exact value for the rounded coordinates (u = 2^-24); 160 u R^2 is subtracted
+                const float Rm = 0.5f * cellLf * (float)max(d0, max(d1, d2));
+                const float d_arith = 160.0f * 5.9604644775390625e-08f * Rm * Rm * (1.0f + 1e-6f);
+                const float qn = __builtin_fmaf(qzf, qzf, __builtin_fmaf(qyf, qyf, qxf * qxf));
+                fs = fminf((fs + qn) - d_arith, s_in);
+                fm = bd;
+            }
+#else
             fs = fminf(fs, s_in);
+#endif
         }
         // ---- merge the four candidate slices of every query
 #pragma unroll
