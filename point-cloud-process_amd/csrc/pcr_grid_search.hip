@@ -1123,10 +1123,18 @@ __host__ __device__ static inline unsigned int pass_item_cap(long long nq) {   /
     return (unsigned int)(((tiles + PASS_GROUPS - 1) / PASS_GROUPS) * (WT_Q + 1));   // + the poison range
 }
 
+// value * 2^F rounded to the nearest integer (ties to even) for |value * 2^F| <= 2^51 -- the host picks F so -- by the
+// add-a-big-constant trick: one multiply-add and one 64-bit subtraction (__double2ll_rn is a ~12-instruction sequence, and
+// every lane of a tile converts 19 moments)
+__device__ static inline long long to_fixed(double v, double scale) {
+    constexpr double BIG = 6755399441055744.0;   // 1.5 * 2^52
+    return __double_as_longlong(__builtin_fma(v, scale, BIG)) - __double_as_longlong(BIG);
+}
+
 // lanes 0..18 of the calling wave add one moment each (one vector atomic instruction); mk = this lane's moment
 __device__ static inline void acc_fixed_add(unsigned long long* __restrict__ acc, unsigned int set, int lane, double mk, double scale) {
     if (lane < PCR_NMOM - 1 && mk != 0.0)
-        atomicAdd(acc + (size_t)(set % ACC_SETS) * PCR_NMOM + lane, (unsigned long long)__double2ll_rn(mk * scale));   // two's complement
+        atomicAdd(acc + (size_t)(set % ACC_SETS) * PCR_NMOM + lane, (unsigned long long)to_fixed(mk, scale));   // two's complement
 }
 
 __device__ static inline void acc_fixed_add_ll(unsigned long long* __restrict__ acc, unsigned int set, int lane, long long v) {
@@ -1329,7 +1337,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         }
         if (lane < WT_Q) {
 #pragma unroll
-            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xll[lane * (PCR_NMOM - 1) + k] = __double2ll_rn(m[k] * A.scale);
+            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xll[lane * (PCR_NMOM - 1) + k] = to_fixed(m[k], A.scale);
         }
         wave_sync();
         long long tot = 0;
@@ -1868,7 +1876,9 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         const double M = (double)nq * fmax(fmax(R * R, params->max_d2), 1.0);
         int ex = 0;
         frexp(M, &ex);              // M < 2^ex
-        const int F = 61 - ex;
+        int exq = 0;
+        frexp(M / (double)nq, &exq);   // one correspondence's moments < 2^exq
+        const int F = (61 - ex < 51 - exq) ? 61 - ex : 51 - exq;   // totals below 2^61, single values below 2^51 (to_fixed)
         if (!(M > 0) || !std::isfinite(M) || F < 20) fused = false;   // absurd extents: keep the binary64 slabs
         else {
             pa.cap = pass_item_cap(nq);
