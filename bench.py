@@ -44,11 +44,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # algorithmic HBM bytes per correspondence of the grid pass:
 # 32 B source record read + 32 B written back in place + 32 B matched target record + 4 B result slot
 GRID_BYTES_PER_CORR = 100.0
-# VALU roofline of the tile kernel's filter (MI355X_MICROARCH.md: 4 SIMD-32 per CU, 2.4 GHz, 157.3 TFLOP/s f32 vector =
-# 256 CUs x 4 SIMDs x 32 lanes x 2 flop): lane-operations the binary32 filter cannot do without, per (query, candidate)
-# pair: 3 subtractions + 1 multiply + 2 fused multiply-adds + 1 minimum
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
-FILTER_LANE_OPS_PER_PAIR = 7.0
+# VALU issue ceiling (MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 binary32 VALU instruction issues over 2 cycles; binary64
+# ones take twice as long, so this ceiling is generous for this kernel's mix)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2    # wave64 VALU instructions per second: one per SIMD every 2 cycles
 BATCH_PAIRS, BATCH_POINTS = 256, 20_000
 
 
@@ -150,10 +148,10 @@ def run_icp_steps(pkg, index, src_host, steps, ctx, sd=None):
 def concurrent_leg(pkg, dev_id, src, tgt, n_pairs, steps):
     """Aggregate throughput with `n_pairs` independent copies of the workload in flight on ONE GPU (one context =
     one HIP stream per pair, one host thread each): what a rank of the batched job (BASELINE configs[3]) does.  A single
-    pair is latency-bound (three dependent launches per iteration); this leg shows the throughput bound."""
+    pair is latency-bound; this leg shows the throughput bound (contexts carry the shared-device hint)."""
     import threading
 
-    ctxs = [pkg.Context(dev_id) for _ in range(n_pairs)]
+    ctxs = [pkg.Context(dev_id, shared=True) for _ in range(n_pairs)]
     work = []
     for c in ctxs:
         idx = pkg.TargetIndex(pkg.DeviceCloud.upload(tgt, c), ctx=c)
@@ -400,16 +398,22 @@ def main():
             "roofline": roofline,
         }
         if a.nn == "grid" and "grid_pass_kernel" in kern:
+            # what actually bounds the pass: VALU issue.  Wave instructions per launch from the committed SQ counter passes (rocprofv3
+            # cannot run inside this process), over this run's kernel duration, against one wave64 VALU instruction per SIMD every 2 cycles.
             try:
+                sqc = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")))["kernels"]["grid_pass_kernel"]
+                n_valu = sqc["SQ_INSTS_VALU"] if a.points == N_POINTS else None
                 fpairs, mean_p = filter_pairs_per_pass(pkg, dev_id, src, tgt, a.cell)
-                tile_s = kern["grid_pass_kernel"] * 1e-6
-                ach = fpairs * FILTER_LANE_OPS_PER_PAIR / tile_s
-                line["roofline_valu"] = {"bound": "valu", "kernel": "grid_pass_kernel", "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
-                                         "unit": "Tlane-op/s (f32)", "frac": ach / VALU_PEAK_LANE_OPS,
+                pass_s = kern["grid_pass_kernel"] * 1e-6
+                line["roofline_valu"] = {"bound": "valu-issue", "kernel": "grid_pass_kernel",
+                                         "achieved": None if n_valu is None else n_valu / pass_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9,
+                                         "unit": "G wave-instructions/s", "frac": None if n_valu is None else n_valu / pass_s / VALU_ISSUE_PEAK,
+                                         "valu_instructions_per_launch": n_valu,
+                                         "source": "profiles/r02_sq_counters.json (SQ_INSTS_VALU, separate rocprofv3 --pmc pass of the same pair)",
                                          "filter_pairs_per_launch": fpairs, "mean_candidates_per_query": mean_p,
-                                         "lane_ops_per_pair": FILTER_LANE_OPS_PER_PAIR,
-                                         "note": "minimal binary32 filter arithmetic over the kernel's measured duration; directory, staging and the "
-                                                 "binary64 verification are overhead on top of it"}
+                                         "note": "whole launch incl. the tail in which most waves wait for the slowest tiles; during the tile stage "
+                                                 "(first ~12 us) the SIMDs issue VALU back to back (DESIGN.md 3.1); the filter itself runs on the "
+                                                 "matrix cores (v_mfma_f32_32x32x2_f32)"}
             except Exception as e:  # diagnostics only
                 line["roofline_valu"] = {"error": repr(e)}
         if batch256 is not None:

@@ -282,6 +282,13 @@ PCR_API int pcr_profile_enable(pcr_ctx* ctx, int on);
  * out[0] = queries the brute-force MFMA sweep could not prove and re-did with the exact direct-form sweep,
  * out[1..3] reserved (0).  Exactness never depends on these numbers; tests use them to see the fallback fire.   */
 PCR_API int pcr_search_stats(pcr_ctx* ctx, int64_t out[4]);
+
+/* Scheduling hint: shared != 0 tells the library that other contexts keep the same device busy while this one runs ICP
+ * loops (a batch worker: Registration/main.py:190-216 spread over several streams).  The ICP pass then runs as two launches
+ * instead of one whose idle waves wait in place for work -- latency for one pair bought with wave slots the other pairs
+ * could use.  Results are identical bit for bit either way.  pcr_icp_batch sets it for its own worker contexts; without
+ * the hint the library still switches by itself while it sees more than one loop of the process in flight. */
+PCR_API int pcr_ctx_set_shared(pcr_ctx* ctx, int shared);
 PCR_API int pcr_profile_read(pcr_ctx* ctx, double ms_out[4], int* passes_out);
 
 #ifdef __cplusplus

@@ -140,6 +140,12 @@ int pcr_profile_read(pcr_ctx* c, double ms_out[4], int* passes_out) {
     return PCR_OK;
 }
 
+int pcr_ctx_set_shared(pcr_ctx* c, int shared) {
+    if (!c) return PCR_E_INVALID;
+    c->shared_device = shared ? 1 : 0;
+    return PCR_OK;
+}
+
 int pcr_search_stats(pcr_ctx* c, int64_t out[4]) {
     if (!c || !out) return PCR_E_INVALID;
     hipSetDevice(c->device);

@@ -1935,7 +1935,7 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             // from the second pass on, res_pos holds the previous pass's neighbours (same query order, same target)
             static const bool no_prev = getenv("PCR_NO_PREV") != nullptr;
             const bool use_prev = enq + c > 0 && !no_prev;
-            const int inline_queue = wait_env >= 0 ? wait_env : (g_loops_in_flight.load(std::memory_order_relaxed) == 1 ? 1 : 0);
+            const int inline_queue = wait_env >= 0 ? wait_env : ((!ctx->shared_device && g_loops_in_flight.load(std::memory_order_relaxed) == 1) ? 1 : 0);
             if (fused) {
                 if (ctx->profile) pcr_prof_mark(ctx, 0);
                 if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)((nq + 63) / 64)), ctx->stream);

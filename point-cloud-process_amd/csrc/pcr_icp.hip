@@ -207,6 +207,12 @@ int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_
     if (!ctxs || n_ctx <= 0 || (n_pairs > 0 && (!pairs || !results)) || !params) return PCR_E_INVALID;
     for (int c = 0; c < n_ctx; ++c)
         if (!ctxs[c]) return PCR_E_INVALID;
+    // several worker contexts keep the device busy together: two-launch ICP passes (pcr_ctx_set_shared); restored on return
+    int was_shared[64];
+    for (int c = 0; c < n_ctx && c < 64; ++c) {
+        was_shared[c] = ctxs[c]->shared_device;
+        if (n_ctx > 1) ctxs[c]->shared_device = 1;
+    }
     std::atomic<int64_t> next(0);
     std::atomic<int> hard_error(PCR_OK);
     static const bool timing = getenv("PCR_BATCH_TIMING") != nullptr;   // diagnostics: mean microseconds per phase and pair
@@ -252,6 +258,7 @@ int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_
         for (int c = 0; c < n_ctx; ++c) pool.emplace_back(worker, ctxs[c]);
         for (auto& t : pool) t.join();
     }
+    for (int c = 0; c < n_ctx && c < 64; ++c) ctxs[c]->shared_device = was_shared[c];
     if (timing && n_pairs > 0)
         fprintf(stderr, "pcr_icp_batch: %lld pairs on %d contexts in %.2f ms; per pair: uploads %.0f us, index build %.0f us, icp %.0f us\n", (long long)n_pairs,
                 n_ctx, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - wall0).count() / 1e3,

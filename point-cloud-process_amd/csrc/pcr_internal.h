@@ -101,6 +101,7 @@ struct pcr_ctx {
     void* h_stage = nullptr;              // pinned staging buffer for uploads from pageable caller memory (grown on demand, <= 64 MiB)
     size_t h_stage_bytes = 0;
     size_t h_pinned_bytes = 0;
+    int shared_device = 0;                // pcr_ctx_set_shared: other contexts keep the device busy (two-launch ICP pass)
     int icp_lanes = 1;                    // runs of the source searched on separate streams per ICP pass (PCR_ICP_LANES)
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     double* h_slabs = nullptr;            // pinned, device-mapped: per-block moment slabs of the host-sum ICP pass

@@ -15,10 +15,16 @@ _lock = threading.Lock()
 class Context:
     """One device + one HIP stream (pcr_ctx).  Not thread-safe, like the C object."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, shared=False):
+        """`shared`: other contexts keep the same device busy while this one registers pairs (see pcr_ctx_set_shared)."""
         self._h = C.c_void_p()
         self.device = int(device)
         L.check(L.lib().pcr_ctx_create(self.device, C.byref(self._h)))
+        if shared:
+            self.set_shared(True)
+
+    def set_shared(self, shared=True):
+        L.check(L.lib().pcr_ctx_set_shared(self.handle, 1 if shared else 0), self.handle)
 
     @property
     def handle(self):

@@ -49,6 +49,8 @@ with open(os.path.join(out, "r02_sq_counters.txt"), "w") as fh:
                                                                         d.get("SQ_INSTS_LDS", 0) / d["SQ_WAVES"], d.get("SQ_INSTS_VMEM_RD", 0) / d["SQ_WAVES"],
                                                                         4 * d["SQ_WAVE_CYCLES"] / d["SQ_WAVES"], 100 * d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"],
                                                                         100 * d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_WAVE_CYCLES"]))
+json.dump({"note": "rocprofv3 --pmc (three passes) -- python3 scripts/prof_pass.py grid 10; mean per launch, whole chip", "kernels": sq},
+          open(os.path.join(out, "r02_sq_counters.json"), "w"), indent=1)
 print(open(os.path.join(out, "r02_sq_counters.txt")).read())
 print(json.dumps(traffic["kernels"], indent=1))
 for name in ("grid", "brute", "bench"):
