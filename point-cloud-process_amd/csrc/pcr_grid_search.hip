@@ -1349,6 +1349,12 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         wave_sync();
     }
     if (dbg) rt_acc = __builtin_amdgcn_s_memrealtime();
+    if (dbg && lane == 0) {   // per-block counters of scripts/wt_stamps.py and bench.py (filter pairs, passes, open queries, cycles)
+        atomicAdd(&dbg[blockIdx.x * 4 + 1], S.dbg_pairs);
+        atomicAdd(&dbg[blockIdx.x * 4 + 2], (unsigned long long)S.dbg_passes);
+        atomicAdd(&dbg[blockIdx.x * 4 + 3], (unsigned long long)__popcll(um));
+        atomicMax(&dbg[blockIdx.x * 4 + 0], __builtin_amdgcn_s_memtime() - t_start);
+    }
     if (!inline_queue) return;   // throughput variant: grid_drain_kernel serves the queues and finishes
     // ---- serve the group's queue
     bool failed = false;
