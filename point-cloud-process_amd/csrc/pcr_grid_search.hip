@@ -1,18 +1,21 @@
 // Exact 1-NN search over the multi-level voxel-hash grid (see pcr_grid.hip for the layout).
 //
-// Queries are processed in WAVE TILES of 16 consecutive records of the Morton-sorted query cloud (a rigid transform
+// Queries are processed in WAVE TILES of 32 consecutive records of the Morton-sorted query cloud (a rigid transform
 // keeps a tile spatially compact, so the cloud is sorted once per pair).
 //
-//   wave tile   one wave per tile, no block-level barrier: box of the cubes its queries claim (cells + 1 ring at first,
-//               bound balls later; inside the ICP loop the previous pass's neighbour bounds every ball at once), directory
-//               through the 2x2x2-block table (one probe per lane), the box's points staged ONCE into the wave's LDS
-//               slice as binary32 coordinates about the box centre, every query compared with every staged point by
-//               packed binary32 math with a rigorous binary64 verification bound; up to three passes.
-//   hard        what a tile cannot prove (ambiguous filter results, balls that need too many cells or points, no
-//               neighbour inside the gate), one wave per query: pruned descent of the nested cell hierarchy (cells are
+//   wave tile   (wtile_search) one wave per tile, no block-level barrier: box of the cubes its queries claim (cells + 1
+//               ring at first, bound balls later; inside the ICP loop the previous pass's neighbour bounds every ball at
+//               once), directory through the 2x2x2-block table (one probe per lane), the box's points staged ONCE into the
+//               wave's LDS slice as binary32 coordinates about the box centre, every query compared with every staged point
+//               on the matrix cores (expanded form) with a rigorous bound on its rounding error, the winner by the direct form.
+//   descent     (hard_search) what a tile cannot prove (ambiguous filter results, balls that need too many cells or points,
+//               no neighbour inside the gate), one wave per query: pruned descent of the nested cell hierarchy (cells are
 //               contiguous runs of the Morton-sorted target at every level), 64 children box-tested per step.
-//   accumulate  gate + Procrustes moments; inside the ICP loop its last block also solves the 3x3 step and tests
-//               convergence, so the host is out of the iteration.
+//   ICP pass    (grid_pass_kernel) ONE launch per iteration of the device-resident loop: tile, moments (fixed point), a
+//               device-side work queue for the open queries served by the waves whose tile is done, and the last wave solves
+//               the 3x3 step and tests convergence, so the host is out of the iteration.  grid_drain_kernel: second launch of
+//               the throughput variant.
+//   stand-alone grid_wtile_kernel -> grid_hard_kernel (-> grid_accumulate_kernel): the nn1 API, ungated runs, the host loop.
 // Round 1's stage was a 64-query tile per 256-thread block (4 barriers per tile, ~980 staged candidates per query, all
 // resident tiles in lockstep): 40 us for the same pass that takes the wave tiles ~30 us with a third of the hard-stage
 // work; DESIGN.md section 7 keeps its measurements.  Measured alternatives before that, all exact, all slower on the
