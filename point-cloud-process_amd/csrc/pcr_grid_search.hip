@@ -225,6 +225,7 @@ struct wt_state {
     bool open, clamped, qvalid;
     unsigned long long dbg_pairs;
     unsigned int dbg_passes;
+    unsigned long long probe;   // *probe_p as read in the middle of the tile's first pass (0 without a probe)
 };
 
 // what a tile needs from memory before anything else: requested in one go by the caller (with whatever else it needs then)
@@ -259,7 +260,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                                                     pcr_pt* __restrict__ q, const long long nq, const pcr_xform& x, const int has_x, const int write_back,
                                                     const double max_d2, const int gated, const unsigned int pcap, unsigned int* __restrict__ res_pos,
                                                     double* __restrict__ res_d2, unsigned long long* __restrict__ dbg,
-                                                    const wt_xyz* __restrict__ prev_xyz, wt_state& S) {
+                                                    const wt_xyz* __restrict__ prev_xyz, wt_state& S, const unsigned long long* probe_p = nullptr) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     const pcr_pt* __restrict__ g_pts = as_global(gv.pts);
@@ -317,7 +318,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
             if (up < bound2) { bound2 = up; cand_pos = pp; }
         }
     }
-    unsigned long long dbg_pairs = 0;
+    unsigned long long dbg_pairs = 0, probe_v = 0;
     unsigned int dbg_passes = 0;
     // seeded tiles (ICP passes after the first) settle 97 % of their queries in pass 0; a third pass only feeds the kernel's tail
     const int max_passes = prev_xyz ? WT_PASSES_SEEDED : WT_PASSES;
@@ -423,6 +424,9 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                 ncell += __popcll(m);
             }
         }
+        // (the one-launch ICP pass wants a device-scope word read here, a few microseconds into the launch -- "have all tiles of my
+        // group started?" -- without paying a round trip for it at the end of the tile)
+        if (probe_p && pass == 0 && lane == 0) probe_v = __hip_atomic_load(probe_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wave_sync();
         WT_STAMP(2);
         // ---- exclusive prefix of the cell counts in slot order (chunks of 64 cells, running total carried along)
@@ -693,6 +697,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
     S.won = won;
     S.open = open; S.clamped = clamped; S.qvalid = qvalid;
     S.dbg_pairs = dbg_pairs; S.dbg_passes = dbg_passes;
+    S.probe = probe_v;
 #ifdef PCR_WT_DIAG
     if (dbg) {
         const bool unres = open && lane < WT_Q;
@@ -1275,7 +1280,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     if (lane == 0) __hip_atomic_fetch_add(g_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody waits for the reply
     // ---- tile
     wt_state S;
-    wtile_search(*gvp, &L->t, tile, lane, P, q, nq, x, 1, 1, max_d2, 1, pcap, res_pos, nullptr, dbg, use_prev ? A.prev_xyz : nullptr, S);
+    wtile_search(*gvp, &L->t, tile, lane, P, q, nq, x, 1, 1, max_d2, 1, pcap, res_pos, nullptr, dbg, use_prev ? A.prev_xyz : nullptr, S, inline_queue ? g_started : nullptr);
     wave_sync();
     if (dbg) rt_tile = __builtin_amdgcn_s_memrealtime();
     // ---- leave the tile stage.  Requested together: the target records of the proven queries (for the moments) and the
@@ -1286,11 +1291,16 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     nb.x = nb.y = nb.z = 0.0; nb.id = 0;
     const bool nb_known = proven && S.won == P.seed_pos;   // same neighbour as in the last pass: its coordinates came with the seed
     if (proven && !nb_known) nb = as_global(gv.pts)[S.won];
+    // every tile of the group started?  Read in the middle of the tile (a launch of one wave generation is complete within a
+    // microsecond, and the count only grows); only if that read came too early is it repeated here
     bool all_started = false;
     if (inline_queue) {
-        unsigned long long sv = 0;
-        if (lane == 0) sv = ld_dev(g_started);
-        all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)sv) == g_tiles;
+        all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)S.probe) == g_tiles;
+        if (!all_started) {
+            unsigned long long sv = 0;
+            if (lane == 0) sv = ld_dev(g_started);
+            all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)sv) == g_tiles;
+        }
     }
     const bool unres = S.open && lane < WT_Q;
     const unsigned long long um = __ballot(unres);
@@ -1407,8 +1417,8 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
             __builtin_amdgcn_s_sleep(4);
         }
         if (failed) break;
-        if (lane < 4 && w != ITEM_NONE) st_dev(it + lane, ITEM_NONE);   // the slot is clean for the next launch
-        if (poisoned) break;
+        if (poisoned) break;   // (the group's last wave cleans the whole poison range: no store, no acknowledgement to wait for here)
+        if (lane < 4) st_dev(it + lane, ITEM_NONE);   // the slot is clean for the next launch
         ++n_items;
         pass_serve_item(gv, L, lane, w, max_d2, A, res_pos, dbg, g + PASS_GROUPS * mine, t_start);
     }

@@ -266,6 +266,45 @@ def test_icp_is_bitwise_reproducible(pcp, syn):
     assert np.array_equal(idx0[0], idx1[0]) and np.array_equal(idx0[1], idx1[1])
 
 
+def test_icp_bits_do_not_depend_on_concurrency(pcp, syn):
+    """Three host threads register the same pair on three contexts of one GPU at the same time (the library switches between
+    the one-launch and the two-launch pass by what it sees in flight, per pass): every result has the bits of the run alone."""
+    import threading
+    src, tgt, _ = syn.perturbed_pair(60000, seed=3)
+    kw = dict(mode="total", max_iter=25, r_thres=-1.0, t_thres=-1.0, min_iter=25)
+    index = pcp.TargetIndex(tgt)
+    sd = pcp.DeviceCloud.upload(src)
+    alone = pcp.icp_device(sd, index, np.eye(4), **kw)
+    want = (alone["T_total"].tobytes(), alone["n_assoc"], sd.download().tobytes())
+    sd.free()
+    index.free()
+    outs, errs = [None] * 3, []
+
+    def run(i):
+        try:
+            c = pcp.Context(0, shared=(i == 2))
+            ix = pcp.TargetIndex(pcp.DeviceCloud.upload(tgt, c), ctx=c)
+            for rep in range(3):
+                d = pcp.DeviceCloud.upload(src, c)
+                r = pcp.icp_device(d, ix, np.eye(4), **kw)
+                outs[i] = (r["T_total"].tobytes(), r["n_assoc"], d.download().tobytes())
+                d.free()
+                if outs[i] != want:
+                    break
+            ix.free()
+            c.close()
+        except Exception as e:   # surfaces in the main thread
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert all(o == want for o in outs)
+
+
 def test_nn1_cell_with_more_than_65535_points(pcp, oracle):
     """A level-0 cell holding > 65535 points overflows the 16-bit child counts of the 2x2x2-block table: the
     directory must fall back to the per-cell table for that block (and the tile goes to the exact descent)."""
