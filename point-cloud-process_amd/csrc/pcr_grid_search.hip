@@ -223,6 +223,7 @@ struct wt_state {
     unsigned int cand_pos;    // the candidate behind bound2 (POS_NONE: only the gate, or nothing, bounds the search)
     unsigned int won;         // proven nearest neighbour; POS_NONE = nothing within the gate, or still open
     bool open, clamped, qvalid;
+    unsigned int staged;      // target points in the tile's boxes, summed over its passes (wave-uniform)
     unsigned long long dbg_pairs;
     unsigned int dbg_passes;
     unsigned long long probe;   // *probe_p as read in the middle of the tile's first pass (0 without a probe)
@@ -319,7 +320,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
         }
     }
     unsigned long long dbg_pairs = 0, probe_v = 0;
-    unsigned int dbg_passes = 0;
+    unsigned int dbg_passes = 0, staged = 0;
     // seeded tiles (ICP passes after the first) settle 97 % of their queries in pass 0; a third pass only feeds the kernel's tail
     const int max_passes = prev_xyz ? WT_PASSES_SEEDED : WT_PASSES;
 #pragma unroll 1
@@ -441,6 +442,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
         }
         wave_sync();
         WT_STAMP(3);
+        staged += total;
         if (total > pcap) { if (part) WT_WHY(2); continue; }   // too many points to stage around this tile: a later pass has tighter balls, or the hard stage takes over
         if (dbg) dbg_pairs += (unsigned long long)total * (unsigned long long)__popcll(__ballot(part && lane < WT_Q));
         const float cellLf = (float)gv.cell0 * (float)(1 << (2 * level));
@@ -696,6 +698,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
     S.cand_pos = cand_pos;
     S.won = won;
     S.open = open; S.clamped = clamped; S.qvalid = qvalid;
+    S.staged = staged;
     S.dbg_pairs = dbg_pairs; S.dbg_passes = dbg_passes;
     S.probe = probe_v;
 #ifdef PCR_WT_DIAG
@@ -1125,6 +1128,7 @@ struct pass_args {
     double scale, inv_scale;              // 2^F, 2^-F
     pcr_icp_dev_state* st;
     pcr_icp_loop_args la;
+    unsigned int* tile_cost;              // [waves]: points every tile staged in the last pass (issue priority of this one)
 };
 __host__ __device__ static inline unsigned int pass_item_cap(long long nq) {   // room for every query of the group's tiles
     const long long tiles = (nq + WT_Q - 1) / WT_Q + 4;
@@ -1263,8 +1267,19 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     // the tile's records and the loop state are requested together; a pass enqueued behind a stop leaves before any side effect
     wt_pre P;
     wtile_preload(tile, lane, q, nq, res_pos, use_prev ? A.prev_xyz : nullptr, P);
+    const unsigned int last_cost = use_prev ? A.tile_cost[tile] : 0u;
     const pcr_xform x = A.st->x;
     if (A.st->stop) return;
+    // The launch ends with its slowest tiles (several staging rounds in the densest part of the scan), and while all tiles run the
+    // SIMDs are VALU-issue bound with four waves each: a tile that was heavy in the last pass gets issue priority over its
+    // neighbours -- those have slack, they would only wait in the work queue.
+    {
+        const unsigned int lc = (unsigned int)__builtin_amdgcn_readfirstlane((int)last_cost);
+        const unsigned int c = lc & 0xffffu, had_open = lc >> 16;   // points staged / queries left open in the last pass
+        if (c > 3 * WT_PR) __builtin_amdgcn_s_setprio(3);
+        else if (c > 2 * WT_PR) __builtin_amdgcn_s_setprio(2);
+        else if (c > WT_PR || had_open) __builtin_amdgcn_s_setprio(1);   // (open queries: the sooner they are queued, the sooner they are served)
+    }
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
     const unsigned long long rt_start = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     unsigned long long rt_tile = 0, rt_acc = 0;
@@ -1282,6 +1297,11 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     wt_state S;
     wtile_search(*gvp, &L->t, tile, lane, P, q, nq, x, 1, 1, max_d2, 1, pcap, res_pos, nullptr, dbg, use_prev ? A.prev_xyz : nullptr, S, inline_queue ? g_started : nullptr);
     wave_sync();
+    __builtin_amdgcn_s_setprio(0);
+    {
+        const unsigned int n_open = (unsigned int)__popcll(__ballot(S.open && lane < WT_Q));   // (a ballot is taken by all lanes)
+        if (lane == 0) A.tile_cost[tile] = (S.staged < 0xffffu ? S.staged : 0xffffu) | (n_open << 16);
+    }
     if (dbg) rt_tile = __builtin_amdgcn_s_memrealtime();
     // ---- leave the tile stage.  Requested together: the target records of the proven queries (for the moments) and the
     // group's started count; then ONE returning add reserves the slots of the open queries, reports the tile done and --
@@ -1305,18 +1325,24 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     const bool unres = S.open && lane < WT_Q;
     const unsigned long long um = __ballot(unres);
     unsigned int mine = 0;     // slot index this wave owns (claimed below, or in the loop)
-    bool have_claim = false, group_done = false;
+    bool have_claim = false;
+    const unsigned int n_groups = n_waves < (unsigned int)PASS_GROUPS ? n_waves : (unsigned int)PASS_GROUPS;
+    unsigned long long* const root = A.sync + (size_t)PASS_SYNC_STRIDE * PASS_GROUPS;
     {
+        // ONE vector atomic: the k-th open query of the tile reserves a slot in group (g + k) mod groups -- a tile in a sparse part of
+        // the scan leaves up to 32 queries open, and all of them in the tile's own group measured 32..250 items per group (the
+        // fullest group finished 9 us after the emptiest) -- and the lane of k = 0 (lane 0 without open queries) also reports the
+        // tile done in its own group and claims the wave's first slot to serve.
+        const unsigned int rank = (unsigned int)__popcll(um & ((1ull << lane) - 1ull));
+        const int own_lane = um ? (int)__ffsll((long long)um) - 1 : 0;
+        const unsigned int tg = unres ? (g + rank) % n_groups : g;
         unsigned long long old = 0;
-        if (lane == 0)
-            old = __hip_atomic_fetch_add(g_q, (1ull << (2 * Q_BITS)) | (all_started ? 1ull << Q_BITS : 0ull) | (unsigned long long)__popcll(um), __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int o_lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)old), o_hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(old >> 32));
-        old = ((unsigned long long)o_hi << 32) | o_lo;
-        const unsigned int base = (unsigned int)(old & Q_MASK);
-        const unsigned int done_before = (unsigned int)(old >> (2 * Q_BITS));
+        if (unres || lane == own_lane)
+            old = __hip_atomic_fetch_add(A.sync + (size_t)PASS_SYNC_STRIDE * tg,
+                                         (unres ? 1ull : 0ull) | (lane == own_lane ? (1ull << (2 * Q_BITS)) | (all_started ? 1ull << Q_BITS : 0ull) : 0ull),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (unres) {
-            unsigned long long* it = items + (size_t)(base + __popcll(um & ((1ull << lane) - 1ull))) * 4;
+            unsigned long long* it = A.items + ((size_t)tg * A.cap + (size_t)(old & Q_MASK)) * 4;
             const bool cand = !S.clamped && S.cand_pos != POS_NONE;
             // a NaN coordinate must not look like "not written yet"
             st_dev(it + 0, S.ax == S.ax ? (unsigned long long)__double_as_longlong(S.ax) : 0x7ff8000000000000ull);
@@ -1324,17 +1350,31 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
             st_dev(it + 2, S.az == S.az ? (unsigned long long)__double_as_longlong(S.az) : 0x7ff8000000000000ull);
             st_dev(it + 3, (unsigned long long)(unsigned int)S.qi | ((unsigned long long)__float_as_uint(cand ? S.bound2 : INFINITY) << 32));
         }
-        const unsigned int R = base + (unsigned int)__popcll(um);
-        if (done_before == g_tiles - 1u && inline_queue) {
-            // last tile of the group: no slot beyond R will ever be filled; whoever holds one reads this and leaves
-            for (unsigned int k = lane; k < g_tiles; k += 64) st_dev(items + (size_t)(R + k) * 4 + 3, ITEM_POISON);
-            group_done = true;
-        }
+        const unsigned int o_lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)old, own_lane), o_hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(old >> 32), own_lane);
+        const unsigned long long own = ((unsigned long long)o_hi << 32) | o_lo;
         if (all_started) {
             have_claim = true;
-            mine = (unsigned int)((old >> Q_BITS) & Q_MASK);
+            mine = (unsigned int)((own >> Q_BITS) & Q_MASK);
         }
-        group_done = group_done && have_claim && mine >= R;   // ... and every slot below R already has its wave: nothing left for this one
+        if ((unsigned int)(own >> (2 * Q_BITS)) == g_tiles - 1u && inline_queue) {
+            // last tile of its group.  The last GROUP to get there knows that every reservation of the launch is in place: it
+            // poisons the slots [R, R + waves of the group) of every group -- whoever waits there holds an index that will never
+            // be filled (each wave exactly one), reads that and leaves.
+            int fin = 0;
+            if (lane == 0) fin = __hip_atomic_fetch_add(root + 8, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n_groups - 1u) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(fin)) {
+                if (lane == 0) st_dev(root + 8, 0ull);
+                unsigned long long qw = 0;
+                if (lane < (int)n_groups) qw = ld_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane);
+                const unsigned int R_l = (unsigned int)(qw & Q_MASK);
+                for (unsigned int gg = 0; gg < n_groups; ++gg) {
+                    const unsigned int R = (unsigned int)__builtin_amdgcn_readlane((int)R_l, (int)gg);
+                    const unsigned int gt = n_waves / PASS_GROUPS + (gg < n_waves % PASS_GROUPS ? 1u : 0u);
+                    unsigned long long* const base_g = A.items + (size_t)gg * A.cap * 4;
+                    for (unsigned int k = lane; k < gt; k += 64) st_dev(base_g + (size_t)(R + k) * 4 + 3, ITEM_POISON);
+                }
+            }
+        }
     }
     // ---- moments of the proven queries.  Every correspondence is rounded to the fixed-point grid ONCE, by itself; from there on
     // only integers are added (here through the wave's LDS slice, then by the atomics): the totals do not depend on how queries
@@ -1371,7 +1411,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     if (!inline_queue) return;   // throughput variant: grid_drain_kernel serves the queues and finishes
     // ---- serve the group's queue
     bool failed = false;
-    while (!group_done) {
+    for (;;) {
         if (!have_claim) {
             if (!all_started) {
                 unsigned long long sv = 0;
@@ -1383,8 +1423,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
                 if (lane == 0) old = __hip_atomic_fetch_add(g_q, 1ull << Q_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned int o_lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)old), o_hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(old >> 32));
                 old = ((unsigned long long)o_hi << 32) | o_lo;
-                mine = (unsigned int)((old >> Q_BITS) & Q_MASK);
-                if ((unsigned int)(old >> (2 * Q_BITS)) == g_tiles && mine >= (unsigned int)(old & Q_MASK)) break;   // group done, nothing left
+                mine = (unsigned int)((old >> Q_BITS) & Q_MASK);   // an item, or the poison, will turn up there
             } else {
                 // tiles of the group are not resident yet: take what is there, never hold a slot waiting for them
                 unsigned long long qw = 0;
@@ -1425,7 +1464,6 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     const unsigned long long rt_loop = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     // ---- the wave that leaves last converts the totals, solves the Procrustes step and tests convergence
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long* const root = A.sync + (size_t)PASS_SYNC_STRIDE * PASS_GROUPS;
     int last = 0;
     {
         int g_last = 0;
@@ -1445,7 +1483,6 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
                 st_dev(g_q, 0ull);
                 st_dev(g_started, 0ull);
                 st_dev(g_ticket, 0ull);
-                const unsigned int n_groups = n_waves < (unsigned int)PASS_GROUPS ? n_waves : (unsigned int)PASS_GROUPS;
                 if (__hip_atomic_fetch_add(root, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n_groups - 1u)) {
                     st_dev(root, 0ull);
                     last = 1;
@@ -1668,6 +1705,7 @@ struct grid_scratch {
     double* res_d2 = nullptr;
     unsigned long long* acc = nullptr;  // [ACC_SETS][PCR_NMOM] fixed-point moment accumulators + [PASS_SYNC_WORDS] queue words (one-kernel pass only)
     unsigned long long* items = nullptr;   // [PASS_GROUPS][pass_item_cap][4] work queue of the one-kernel pass
+    unsigned int* tile_cost = nullptr;     // [waves of the pass]
     void* prev_xyz = nullptr;         // [nq] x 24 B: coordinates of every query's neighbour of the last ICP pass (device loop only)
     work_item* hard_list = nullptr;   // [nq] worst case
     unsigned int* hard_count = nullptr;
@@ -1699,6 +1737,8 @@ static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
     if (sc->hard_list) pcr_dev_free(ctx, sc->hard_list, sizeof(work_item) * (size_t)H_NLIST * hard_list_cap(sc->nq));
     if (sc->prev_xyz) pcr_dev_free(ctx, sc->prev_xyz, 24 * (size_t)sc->nq);
     if (sc->items) pcr_dev_free(ctx, sc->items, 32 * (size_t)PASS_GROUPS * pass_item_cap(sc->nq));
+    if (sc->tile_cost) pcr_dev_free(ctx, sc->tile_cost, sizeof(unsigned int) * (size_t)((sc->nq + 4 * WT_Q - 1) / (4 * WT_Q)) * 4);
+    sc->tile_cost = nullptr;
     if (sc->acc) pcr_dev_free(ctx, sc->acc, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS));
     sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr; sc->prev_xyz = nullptr; sc->items = nullptr; sc->acc = nullptr;
 }
@@ -1902,11 +1942,13 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         else {
             pa.cap = pass_item_cap(nq);
             if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS), (void**)&sc.acc)) ||
+                (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (size_t)((nq + 4 * WT_Q - 1) / (4 * WT_Q)) * 4, (void**)&sc.tile_cost)) ||
                 (rc = pcr_dev_alloc(ctx, 32 * (size_t)PASS_GROUPS * pa.cap, (void**)&sc.items))) {
                 grid_scratch_free(ctx, &sc);
                 return rc;
             }
             pa.items = sc.items;
+            pa.tile_cost = sc.tile_cost;
             pa.acc = sc.acc;
             pa.sync = sc.acc + ACC_SETS * PCR_NMOM;
             pa.prev_xyz = (wt_xyz*)sc.prev_xyz;

@@ -54,3 +54,18 @@ if ph.sum() > 0:   # -DPCR_WT_DIAG build: phase cycles of wave 0 of every block 
     tot = ph.sum(axis=1)
     heavy = tot >= np.percentile(tot, 97)
     print("the heaviest 3 %% of these waves (%d): mean cycles per phase" % heavy.sum(), {nm: int(ph[heavy, i].mean()) for i, nm in enumerate(names[:7])}, "total", int(tot[heavy].mean()))
+# per queue group (wave id after the XCD remap, mod 32): items served and when the group's last wave left
+nblk = nw // 4
+per = nblk >> 3; main = per << 3
+raw = np.arange(nw)
+blk = raw // 4
+blk2 = np.where(blk < main, (blk & 7) * per + (blk >> 3), blk)
+wid = blk2 * 4 + (raw & 3)
+grp = wid % 32
+it_g = np.bincount(grp, weights=w[:, 4], minlength=32)
+ex_g = np.array([us(w[grp == g, 3]).max() for g in range(32)])
+last_tile_g = np.array([us(w[grp == g, 1]).max() for g in range(32)])
+print("items per group min/median/max", int(it_g.min()), int(np.median(it_g)), int(it_g.max()), "| group's last queue exit us min/median/max %.1f %.1f %.1f" % (ex_g.min(), np.median(ex_g), ex_g.max()),
+      "| last tile end per group min/max %.1f %.1f" % (last_tile_g.min(), last_tile_g.max()))
+busy = w[:, 4] > 0
+print("waves that served items: exit us pct 50/90/99/max", pc(us(w[busy, 3])), " idle ones:", pc(us(w[~busy, 3])))
