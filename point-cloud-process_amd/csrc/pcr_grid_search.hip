@@ -226,7 +226,7 @@ struct wt_state {
     unsigned int staged;      // target points in the tile's boxes, summed over its passes (wave-uniform)
     unsigned long long dbg_pairs;
     unsigned int dbg_passes;
-    unsigned long long probe;   // *probe_p as read in the middle of the tile's first pass (0 without a probe)
+    unsigned long long probe;   // 1: the probe words (started counts of all groups) read in the middle of the tile's first pass were all complete
 };
 
 // what a tile needs from memory before anything else: requested in one go by the caller (with whatever else it needs then)
@@ -261,7 +261,8 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                                                     pcr_pt* __restrict__ q, const long long nq, const pcr_xform& x, const int has_x, const int write_back,
                                                     const double max_d2, const int gated, const unsigned int pcap, unsigned int* __restrict__ res_pos,
                                                     double* __restrict__ res_d2, unsigned long long* __restrict__ dbg,
-                                                    const wt_xyz* __restrict__ prev_xyz, wt_state& S, const unsigned long long* probe_p = nullptr) {
+                                                    const wt_xyz* __restrict__ prev_xyz, wt_state& S, const unsigned long long* probe_p = nullptr,
+                                                    const unsigned int probe_stride = 0, const unsigned int probe_groups = 0, const unsigned int probe_total = 0) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     const pcr_pt* __restrict__ g_pts = as_global(gv.pts);
@@ -425,9 +426,10 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                 ncell += __popcll(m);
             }
         }
-        // (the one-launch ICP pass wants a device-scope word read here, a few microseconds into the launch -- "have all tiles of my
-        // group started?" -- without paying a round trip for it at the end of the tile)
-        if (probe_p && pass == 0 && lane == 0) probe_v = __hip_atomic_load(probe_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the one-launch ICP pass wants device-scope words read here, a few microseconds into the launch -- "have all tiles of the
+        // launch started?": the started count of every group -- without paying a round trip for them at the end of the tile)
+        if (probe_p && pass == 0 && lane < (int)probe_groups)   // one word per group, compared after the tile: nobody waits for it here
+            probe_v = __hip_atomic_load(probe_p + (size_t)probe_stride * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wave_sync();
         WT_STAMP(2);
         // ---- exclusive prefix of the cell counts in slot order (chunks of 64 cells, running total carried along)
@@ -700,7 +702,10 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
     S.open = open; S.clamped = clamped; S.qvalid = qvalid;
     S.staged = staged;
     S.dbg_pairs = dbg_pairs; S.dbg_passes = dbg_passes;
-    S.probe = probe_v;
+    {   // probe: every group's count complete?  (group l has total / groups tiles, the first total % groups groups one more)
+        const bool ok = lane < (int)probe_groups && (unsigned int)probe_v == probe_total / (probe_groups ? probe_groups : 1u) + ((unsigned int)lane < probe_total % (probe_groups ? probe_groups : 1u) ? 1u : 0u);
+        S.probe = (probe_groups && __ballot(ok) == (probe_groups >= 64 ? ~0ull : (1ull << probe_groups) - 1ull)) ? 1ull : 0ull;
+    }
 #ifdef PCR_WT_DIAG
     if (dbg) {
         const bool unres = open && lane < WT_Q;
@@ -1083,24 +1088,27 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
 // Everything waves tell each other INSIDE the launch goes through device-scope atomics (performed at the coherence
 // point: the L2 of another XCD never holds a stale copy) and never needs a fence (an agent-scope release is an L2
 // write-back on this chip: 2048 blocks doing one cost 40 us):
-//   queue     32 groups (tile t belongs to group t % 32).  Per group ONE 64-bit word
+//   queue     32 groups (wave w belongs to group w % 32).  Per group ONE 64-bit word
 //                 done << 44 | claimed << 22 | reserved
-//             (tiles of the group through with their tile stage; slot indices handed out; slots reserved).  A tile reserves
-//             its slots and reports itself done with ONE returning add, then stores its items; every 8-byte word of an item is
-//             self-validating (all-ones = not written yet; the consumer puts that back), so no ordering between the words or
-//             against the counter is needed.
-//   claims    a free wave takes the NEXT slot index with one returning add -- whether or not an item is there yet -- and
-//             then polls ITS OWN slot: waiting waves sit on private addresses, an item lands in front of the wave that
-//             serves it, and the group word only sees one add per tile and per claim.  (Polling the group word and claiming
+//             (tiles of the group through with their tile stage; slot indices handed out; slots reserved).  A tile leaves its
+//             stage with ONE vector atomic: its k-th open query reserves a slot in group (g + k) % 32 (a tile in a sparse part of
+//             the scan leaves up to 32 queries open: all in its own group measured 32..250 items per group), the lane of k = 0
+//             also reports the tile done in its own group and claims the wave's first slot to serve.  Then it stores its items;
+//             every 8-byte word of an item is self-validating (all-ones = not written yet; the consumer puts that back), so no
+//             ordering between the words or against the counter is needed.
+//   claims    a free wave takes the NEXT slot index of its group with one returning add -- whether or not an item is there yet --
+//             and then polls ITS OWN slot: waiting waves sit on private addresses, an item lands in front of the wave that
+//             serves it, and the group word only sees one add per reservation and per claim.  (Polling the group word and claiming
 //             by compare-and-swap measured 430 us per pass with 117 waves per word, 88 us with 15: same-address accesses
-//             serialise at the memory side at ~100 ns each, and few waves per group balance badly.)  The tile that reports
-//             done last knows the final slot count R and POISONS the slots [R, R + tiles of the group): every wave still
-//             waiting (each holds exactly one index >= R) reads that and leaves.
-//   waiting   holding an index means waiting for it, and a wave may only WAIT if every tile of its group has started (they
-//             are resident and will finish): on a busy GPU (several pairs in flight, clouds of several wave generations)
-//             waiting waves would keep the slots the missing tiles need.  Until the group has started completely a free
-//             wave therefore only takes items that are already there (compare-and-swap while claimed < reserved) and
-//             leaves otherwise.  Progress: the tile that finishes last drains the queue itself.
+//             serialise at the memory side at ~100 ns each, and few waves per group balance badly.)  When the last tile of the
+//             last group has reported done, every reservation of the launch is in place: that wave reads the final slot counts R
+//             and POISONS the slots [R, R + waves of the group) of every group; every wave still waiting (each holds exactly one
+//             index >= R) reads that and leaves.
+//   waiting   holding an index means waiting for it -- for an item from ANY tile, or for the poison that needs every tile -- so a
+//             wave may only WAIT if every tile of the launch has started (they are resident and will finish): on a busy GPU
+//             (several pairs in flight, clouds of several wave generations) waiting waves would keep the slots the missing tiles
+//             need.  Until then a free wave only takes items that are already there (compare-and-swap while claimed < reserved)
+//             and leaves otherwise.  Progress: the last generation of waves waits, and serves what the earlier ones left.
 //   variants  inline_queue = 0: the launch only publishes and grid_drain_kernel (below) serves the queues -- the host's choice
 //             while several ICP loops of the process are in flight; same results bit for bit.
 //   finish    vmcnt(0) (own atomics acknowledged), then a two-level ticket (one word per group, then a root).
@@ -1114,7 +1122,12 @@ constexpr int ACC_SETS = PCR_ACC_SETS;
 constexpr int PASS_GROUPS = PCR_PASS_GROUPS;
 constexpr int PASS_SYNC_STRIDE = 32;                      // 64-bit words per group: queue word at 0, started at 16, ticket at 17 (other line)
 constexpr int PASS_SYNC_WORDS = PASS_SYNC_STRIDE * (PASS_GROUPS + 1);   // + root ticket (0) / error word (16)
-constexpr unsigned long long ITEM_NONE = ~0ull, ITEM_POISON = ~0ull - 1ull;   // neither is a valid last word of an item (query index 2^32 - 1 / 2^32 - 2)
+constexpr unsigned long long ITEM_NONE = ~0ull;           // "not written yet": never a valid word of an item
+// Last word of an item = query index | binary32 bits of its candidate's bound << 32 (finite, or +inf).  A POISON word carries 0xfffffffe
+// (no such bound) above the id of the pass that wrote it: poison of an earlier pass reads as "not written yet", so nobody ever has to
+// clean it up (the whole queue is re-initialised per ICP call).
+constexpr unsigned int POISON_HI = 0xfffffffeu;
+__device__ static inline unsigned long long item_poison(unsigned int pass_id) { return ((unsigned long long)POISON_HI << 32) | pass_id; }
 constexpr unsigned int PASS_SPIN_LIMIT = 1u << 18;        // polls before a wave gives up and flags an error (never seen)
 constexpr int Q_BITS = 22;                                // reserved / claimed fields; done has the upper 20 bits
 constexpr unsigned long long Q_MASK = (1ull << Q_BITS) - 1ull;
@@ -1129,6 +1142,7 @@ struct pass_args {
     pcr_icp_dev_state* st;
     pcr_icp_loop_args la;
     unsigned int* tile_cost;              // [waves]: points every tile staged in the last pass (issue priority of this one)
+    unsigned int pass_id;                 // passes enqueued so far in this ICP call
 };
 __host__ __device__ static inline unsigned int pass_item_cap(long long nq) {   // room for every query of the group's tiles
     const long long tiles = (nq + WT_Q - 1) / WT_Q + 4;
@@ -1293,9 +1307,11 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     unsigned long long* const g_ticket = g_q + 17;
     unsigned long long* const items = A.items + (size_t)g * A.cap * 4;
     if (lane == 0) __hip_atomic_fetch_add(g_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody waits for the reply
+    const unsigned int n_groups = n_waves < (unsigned int)PASS_GROUPS ? n_waves : (unsigned int)PASS_GROUPS;
     // ---- tile
     wt_state S;
-    wtile_search(*gvp, &L->t, tile, lane, P, q, nq, x, 1, 1, max_d2, 1, pcap, res_pos, nullptr, dbg, use_prev ? A.prev_xyz : nullptr, S, inline_queue ? g_started : nullptr);
+    wtile_search(*gvp, &L->t, tile, lane, P, q, nq, x, 1, 1, max_d2, 1, pcap, res_pos, nullptr, dbg, use_prev ? A.prev_xyz : nullptr, S, inline_queue ? A.sync + 16 : nullptr,
+                 (unsigned int)PASS_SYNC_STRIDE, n_groups, n_waves);
     wave_sync();
     __builtin_amdgcn_s_setprio(0);
     {
@@ -1311,38 +1327,40 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     nb.x = nb.y = nb.z = 0.0; nb.id = 0;
     const bool nb_known = proven && S.won == P.seed_pos;   // same neighbour as in the last pass: its coordinates came with the seed
     if (proven && !nb_known) nb = as_global(gv.pts)[S.won];
-    // every tile of the group started?  Read in the middle of the tile (a launch of one wave generation is complete within a
-    // microsecond, and the count only grows); only if that read came too early is it repeated here
+    // Every tile of the LAUNCH started?  (A wave that waits for work waits for items from any tile: all of them must be resident.)
+    // Read in the middle of the tile -- a launch of one wave generation is complete within a microsecond, and the counts only
+    // grow --; only if that read came too early is it repeated here.
     bool all_started = false;
     if (inline_queue) {
-        all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)S.probe) == g_tiles;
+        all_started = S.probe != 0;
         if (!all_started) {
             unsigned long long sv = 0;
-            if (lane == 0) sv = ld_dev(g_started);
-            all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)sv) == g_tiles;
+            if (lane < (int)n_groups) sv = ld_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 16);
+            const bool ok = lane < (int)n_groups && (unsigned int)sv == n_waves / PASS_GROUPS + ((unsigned int)lane < n_waves % PASS_GROUPS ? 1u : 0u);
+            all_started = __ballot(ok) == (n_groups >= 64 ? ~0ull : (1ull << n_groups) - 1ull);
         }
     }
     const bool unres = S.open && lane < WT_Q;
     const unsigned long long um = __ballot(unres);
     unsigned int mine = 0;     // slot index this wave owns (claimed below, or in the loop)
     bool have_claim = false;
-    const unsigned int n_groups = n_waves < (unsigned int)PASS_GROUPS ? n_waves : (unsigned int)PASS_GROUPS;
     unsigned long long* const root = A.sync + (size_t)PASS_SYNC_STRIDE * PASS_GROUPS;
     {
-        // ONE vector atomic: the k-th open query of the tile reserves a slot in group (g + k) mod groups -- a tile in a sparse part of
-        // the scan leaves up to 32 queries open, and all of them in the tile's own group measured 32..250 items per group (the
-        // fullest group finished 9 us after the emptiest) -- and the lane of k = 0 (lane 0 without open queries) also reports the
-        // tile done in its own group and claims the wave's first slot to serve.
+        // The k-th open query of the tile reserves a slot in group (g + k) mod groups, all of them by ONE vector atomic -- a tile in a
+        // sparse part of the scan leaves up to 32 queries open, and all of them in the tile's own group measured 32..250 items per
+        // group (the fullest group finished 9 us after the emptiest).  Only when the replies are back -- the reservations are in
+        // place -- does lane 0 report the tile done in its own group (and claim the wave's first slot to serve): "every tile done"
+        // must imply "every reservation made", or the poison below could land in a slot that is reserved a moment later.
         const unsigned int rank = (unsigned int)__popcll(um & ((1ull << lane) - 1ull));
-        const int own_lane = um ? (int)__ffsll((long long)um) - 1 : 0;
-        const unsigned int tg = unres ? (g + rank) % n_groups : g;
-        unsigned long long old = 0;
-        if (unres || lane == own_lane)
-            old = __hip_atomic_fetch_add(A.sync + (size_t)PASS_SYNC_STRIDE * tg,
-                                         (unres ? 1ull : 0ull) | (lane == own_lane ? (1ull << (2 * Q_BITS)) | (all_started ? 1ull << Q_BITS : 0ull) : 0ull),
-                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int tg = (g + rank) % n_groups;
+        unsigned long long slot_w = 0;
+        if (unres) slot_w = __hip_atomic_fetch_add(A.sync + (size_t)PASS_SYNC_STRIDE * tg, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" :: "v"(slot_w) : "memory");   // replies first
+        unsigned long long own = 0;
+        if (lane == 0)
+            own = __hip_atomic_fetch_add(g_q, (1ull << (2 * Q_BITS)) | (all_started ? 1ull << Q_BITS : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (unres) {
-            unsigned long long* it = A.items + ((size_t)tg * A.cap + (size_t)(old & Q_MASK)) * 4;
+            unsigned long long* it = A.items + ((size_t)tg * A.cap + (size_t)(slot_w & Q_MASK)) * 4;
             const bool cand = !S.clamped && S.cand_pos != POS_NONE;
             // a NaN coordinate must not look like "not written yet"
             st_dev(it + 0, S.ax == S.ax ? (unsigned long long)__double_as_longlong(S.ax) : 0x7ff8000000000000ull);
@@ -1350,8 +1368,10 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
             st_dev(it + 2, S.az == S.az ? (unsigned long long)__double_as_longlong(S.az) : 0x7ff8000000000000ull);
             st_dev(it + 3, (unsigned long long)(unsigned int)S.qi | ((unsigned long long)__float_as_uint(cand ? S.bound2 : INFINITY) << 32));
         }
-        const unsigned int o_lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)old, own_lane), o_hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(old >> 32), own_lane);
-        const unsigned long long own = ((unsigned long long)o_hi << 32) | o_lo;
+        {
+            const unsigned int o_lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)own), o_hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(own >> 32));
+            own = ((unsigned long long)o_hi << 32) | o_lo;
+        }
         if (all_started) {
             have_claim = true;
             mine = (unsigned int)((own >> Q_BITS) & Q_MASK);
@@ -1371,7 +1391,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
                     const unsigned int R = (unsigned int)__builtin_amdgcn_readlane((int)R_l, (int)gg);
                     const unsigned int gt = n_waves / PASS_GROUPS + (gg < n_waves % PASS_GROUPS ? 1u : 0u);
                     unsigned long long* const base_g = A.items + (size_t)gg * A.cap * 4;
-                    for (unsigned int k = lane; k < gt; k += 64) st_dev(base_g + (size_t)(R + k) * 4 + 3, ITEM_POISON);
+                    for (unsigned int k = lane; k < gt; k += 64) st_dev(base_g + (size_t)(R + k) * 4 + 3, item_poison(A.pass_id));
                 }
             }
         }
@@ -1415,8 +1435,9 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         if (!have_claim) {
             if (!all_started) {
                 unsigned long long sv = 0;
-                if (lane == 0) sv = ld_dev(g_started);
-                all_started = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)sv) == g_tiles;
+                if (lane < (int)n_groups) sv = ld_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 16);
+                const bool ok = lane < (int)n_groups && (unsigned int)sv == n_waves / PASS_GROUPS + ((unsigned int)lane < n_waves % PASS_GROUPS ? 1u : 0u);
+                all_started = __ballot(ok) == (n_groups >= 64 ? ~0ull : (1ull << n_groups) - 1ull);
             }
             if (all_started) {
                 unsigned long long old = 0;
@@ -1447,9 +1468,10 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         bool poisoned = false;
         for (unsigned int spins = 0;; ++spins) {
             if (lane < 4) w = ld_dev(it + lane);
-            const unsigned long long mk = __ballot(lane < 4 && w != ITEM_NONE);
-            poisoned = __builtin_amdgcn_readlane((int)(unsigned int)w, 3) == (int)(unsigned int)ITEM_POISON &&
-                       __builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), 3) == (int)(unsigned int)(ITEM_POISON >> 32);
+            // word 3: this pass's poison -> leave; an earlier pass's -> as good as not written
+            const unsigned int w3_lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w, 3), w3_hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), 3);
+            poisoned = w3_hi == POISON_HI && w3_lo == A.pass_id;
+            const unsigned long long mk = __ballot(lane < 4 && w != ITEM_NONE && !(lane == 3 && w3_hi == POISON_HI));
             if (poisoned || mk == 0xfull) break;
             if (spins >= PASS_SPIN_LIMIT) { failed = true; break; }
             ++n_polls;
@@ -1466,28 +1488,11 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int last = 0;
     {
-        int g_last = 0;
-        unsigned long long qw = 0;
         if (lane == 0) {
             if (failed) st_dev(root + 16, 1ull);
-            if (__hip_atomic_fetch_add(g_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(g_tiles - 1u)) {
-                g_last = 1;
-                qw = ld_dev(g_q);
-            }
-        }
-        if (__builtin_amdgcn_readfirstlane(g_last)) {
-            // everybody of the group is through with its words and slots: clean for the next launch (poison nobody read included)
-            const unsigned int R = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(qw & Q_MASK));
-            for (unsigned int k = lane; k < g_tiles; k += 64) st_dev(items + (size_t)(R + k) * 4 + 3, ITEM_NONE);
-            if (lane == 0) {
-                st_dev(g_q, 0ull);
-                st_dev(g_started, 0ull);
-                st_dev(g_ticket, 0ull);
-                if (__hip_atomic_fetch_add(root, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n_groups - 1u)) {
-                    st_dev(root, 0ull);
-                    last = 1;
-                }
-            }
+            if (__hip_atomic_fetch_add(g_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(g_tiles - 1u) &&
+                __hip_atomic_fetch_add(root, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n_groups - 1u))
+                last = 1;
         }
     }
     if (dbg && lane == 0) {
@@ -1495,6 +1500,39 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         d[0] = rt_start; d[1] = rt_tile; d[2] = rt_acc; d[3] = rt_loop; d[4] = n_items; d[5] = n_polls | ((unsigned long long)n_casfail << 32); d[6] = S.dbg_pairs | ((unsigned long long)S.dbg_passes << 40) | ((unsigned long long)__popcll(um) << 48); d[7] = __builtin_amdgcn_s_memrealtime();
     }
     if (!__builtin_amdgcn_readfirstlane(last)) return;
+    // ---- last wave of the launch.  Normally every item has been claimed and served by now.  But nobody is OBLIGED to wait for work
+    // (a wave that cannot see every tile of the launch started leaves when it finds nothing), so items reserved after the last wave of
+    // their group left may still sit in the queue: serve them here, then clean the queue words for the next launch.
+    {
+        unsigned long long qw = 0;
+        if (lane < (int)n_groups) qw = ld_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane);
+        const unsigned int r_l = (unsigned int)(qw & Q_MASK), c_l = (unsigned int)((qw >> Q_BITS) & Q_MASK);
+        unsigned long long left = __ballot(lane < (int)n_groups && c_l < r_l);
+        while (left) {
+            const int gg = (int)__ffsll((long long)left) - 1;
+            left &= left - 1;
+            const unsigned int c0 = (unsigned int)__builtin_amdgcn_readlane((int)c_l, gg), r0 = (unsigned int)__builtin_amdgcn_readlane((int)r_l, gg);
+            for (unsigned int i = c0; i < r0; ++i) {
+                unsigned long long* it = A.items + ((size_t)gg * A.cap + i) * 4;
+                unsigned long long w = ITEM_NONE;
+                for (unsigned int spins = 0; spins < PASS_SPIN_LIMIT; ++spins) {
+                    if (lane < 4) w = ld_dev(it + lane);
+                    const unsigned int w3_hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), 3);
+                    if (__ballot(lane < 4 && w != ITEM_NONE && !(lane == 3 && w3_hi == POISON_HI)) == 0xfull) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (lane < 4) st_dev(it + lane, ITEM_NONE);
+                pass_serve_item(gv, L, lane, w, max_d2, A, res_pos, dbg, 59999u, t_start);
+            }
+        }
+        if (lane < (int)n_groups) {
+            st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane, 0ull);
+            st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 16, 0ull);
+            st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 17, 0ull);
+        }
+        if (lane == 0) st_dev(root, 0ull);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the leftovers' atomics, if any)
+    }
     pass_finish(gv, L, lane, A, root, dbg);
 }
 
@@ -1996,11 +2034,16 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             // from the second pass on, res_pos holds the previous pass's neighbours (same query order, same target)
             static const bool no_prev = getenv("PCR_NO_PREV") != nullptr;
             const bool use_prev = enq + c > 0 && !no_prev;
-            const int inline_queue = wait_env >= 0 ? wait_env : ((!ctx->shared_device && g_loops_in_flight.load(std::memory_order_relaxed) == 1) ? 1 : 0);
+            // one launch only when it is a single generation of waves (16 per CU at <= 128 VGPRs) with the device to itself: in a
+            // launch of several generations most waves may not wait for work (the later tiles need their slots), and the queue
+            // would be served by the last generation alone (1 M points: 2.4 ms per pass against 0.32 ms for two launches)
+            const bool one_generation = (nq + WT_Q - 1) / WT_Q <= 16ll * ctx->cu_count;
+            const int inline_queue = wait_env >= 0 ? wait_env : ((one_generation && !ctx->shared_device && g_loops_in_flight.load(std::memory_order_relaxed) == 1) ? 1 : 0);
             if (fused) {
                 if (ctx->profile) pcr_prof_mark(ctx, 0);
                 if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)((nq + 63) / 64)), ctx->stream);
                 const int wblocks = (int)((nq + 4 * WT_Q - 1) / (4 * WT_Q));
+                pa.pass_id = (unsigned int)(enq + c);
                 hipLaunchKernelGGL(grid_pass_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, (const pcr_grid_view*)idx->d_view, idx->view, qc->d, (long long)nq,
                                    params->max_d2, wtile_xcd_remap(), wtile_point_cap(ctx, nq), sc.res_pos, ctx->d_debug, use_prev ? 1 : 0, inline_queue, pa);
                 if (ctx->profile) pcr_prof_mark(ctx, 1);

@@ -266,6 +266,31 @@ def test_icp_is_bitwise_reproducible(pcp, syn):
     assert np.array_equal(idx0[0], idx1[0]) and np.array_equal(idx0[1], idx1[1])
 
 
+@pytest.mark.parametrize("n", [140000, 400000])
+def test_icp_bits_across_wave_generations(pcp, syn, n):
+    """Clouds whose ICP pass is more than one generation of waves (> 131 072 points on 256 CUs): the library takes the two-launch
+    variant there; forced into the one-launch variant most waves may not wait for work, late items are served by whoever is
+    left and, at the latest, by the launch's last wave.  Same bits every time and in both variants."""
+    import os
+    src, tgt, _ = syn.perturbed_pair(n, seed=0)
+    index = pcp.TargetIndex(tgt)
+    kw = dict(mode="total", max_iter=8, r_thres=-1.0, t_thres=-1.0, min_iter=8)
+    outs = []
+    try:
+        for v in (None, None, "1", "1", "0"):
+            if v is None:
+                os.environ.pop("PCR_PASS_INLINE", None)
+            else:
+                os.environ["PCR_PASS_INLINE"] = v
+            sd = pcp.DeviceCloud.upload(src)
+            r = pcp.icp_device(sd, index, np.eye(4), **kw)
+            outs.append((r["T_total"].tobytes(), int(r["n_assoc"]), sd.download().tobytes()))
+            sd.free()
+    finally:
+        os.environ.pop("PCR_PASS_INLINE", None)
+    assert all(o == outs[0] for o in outs[1:])
+
+
 def test_icp_bits_do_not_depend_on_concurrency(pcp, syn):
     """Three host threads register the same pair on three contexts of one GPU at the same time (the library switches between
     the one-launch and the two-launch pass by what it sees in flight, per pass): every result has the bits of the run alone."""
