@@ -1128,7 +1128,7 @@ constexpr unsigned long long ITEM_NONE = ~0ull;           // "not written yet": 
 // clean it up (the whole queue is re-initialised per ICP call).
 constexpr unsigned int POISON_HI = 0xfffffffeu;
 __device__ static inline unsigned long long item_poison(unsigned int pass_id) { return ((unsigned long long)POISON_HI << 32) | pass_id; }
-constexpr unsigned int PASS_SPIN_LIMIT = 1u << 18;        // polls before a wave gives up and flags an error (never seen)
+constexpr unsigned int PASS_SPIN_LIMIT = 1u << 21;        // polls (>= 1 us each) before a wave gives up and flags an error (never seen)
 constexpr int Q_BITS = 22;                                // reserved / claimed fields; done has the upper 20 bits
 constexpr unsigned long long Q_MASK = (1ull << Q_BITS) - 1ull;
 constexpr long long PASS_MAX_NQ = 1ll << 26;              // 32 groups x 2^22 slots, with room for the poison range
