@@ -306,6 +306,8 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
+    if world > 1 and a.device >= 0:   # rehearsal: several ranks on ONE GPU (tell the library, see pcr_ctx_set_shared)
+        ctx.set_shared(True)
     run_icp_steps(pkg, index, src, a.warmup, ctx)  # untimed warm-up
     if dist is not None:  # warm the collective too (communicator and kernel set-up are one-off costs)
         wrec = torch.zeros(18, dtype=torch.float64, device=tdev)
