@@ -1235,8 +1235,9 @@ __device__ __forceinline__ static void pass_finish(const pcr_grid_view& gv, pass
     constexpr int HEAD_WORDS = (int)(pcr::ICP_STATE_HEAD_BYTES / 8);
     static_assert(pcr::ICP_STATE_HEAD_BYTES % 8 == 0 && HEAD_WORDS <= 64, "state head: one word per lane");
     double* const head = L->xch + 32;   // 16-byte aligned, behind the 20 moments
-    unsigned long long hw = 0;
+    unsigned long long hw = 0, err_w = 0;
     if (lane < HEAD_WORDS) hw = reinterpret_cast<const unsigned long long*>(A.st)[lane];
+    if (lane == 63) err_w = ld_dev(root + 16);   // (with the other loads: one round trip)
     const int mom = lane % PCR_NMOM, part = lane / PCR_NMOM;
     long long sum = 0;
     if (part < 3) {
@@ -1260,10 +1261,11 @@ __device__ __forceinline__ static void pass_finish(const pcr_grid_view& gv, pass
     if (dbg && lane == 0) dbg[(1 << 19) - 3] = __builtin_amdgcn_s_memrealtime();
     if (lane < PCR_NMOM) L->xch[lane] = (double)sum * A.inv_scale;
     if (lane < HEAD_WORDS) reinterpret_cast<unsigned long long*>(head)[lane] = hw;
+    const bool gave_up = __builtin_amdgcn_readlane((int)(unsigned int)err_w, 63) != 0;
     wave_sync();
     if (lane == 0) {
         pcr_icp_dev_state* hs = reinterpret_cast<pcr_icp_dev_state*>(head);
-        if (ld_dev(root + 16)) { hs->status = PCR_E_HIP; hs->stop = 1; st_dev(root + 16, 0ull); }
+        if (gave_up) { hs->status = PCR_E_HIP; hs->stop = 1; st_dev(root + 16, 0ull); }
         else pcr::icp_step(hs, L->xch, gv.origin, A.la, A.st->r_diff, A.st->t_diff);
     }
     wave_sync();
@@ -1430,7 +1432,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     }
     if (!inline_queue) return;   // throughput variant: grid_drain_kernel serves the queues and finishes
     // ---- serve the group's queue
-    bool failed = false;
+    bool failed = false, left_by_poison = false;
     for (;;) {
         if (!have_claim) {
             if (!all_started) {
@@ -1478,7 +1480,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
             __builtin_amdgcn_s_sleep(4);
         }
         if (failed) break;
-        if (poisoned) break;   // (the group's last wave cleans the whole poison range: no store, no acknowledgement to wait for here)
+        if (poisoned) { left_by_poison = true; break; }
         if (lane < 4) st_dev(it + lane, ITEM_NONE);   // the slot is clean for the next launch
         ++n_items;
         pass_serve_item(gv, L, lane, w, max_d2, A, res_pos, dbg, g + PASS_GROUPS * mine, t_start);
@@ -1488,22 +1490,29 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int last = 0;
     {
+        // Tickets carry a second count in their upper half: waves that left the queue by reading the poison.  Such a wave held an
+        // index >= the final slot count of its group, so every slot below it had been claimed: a group with one of them has nothing
+        // unclaimed, and when every group has one the last wave need not look at the queue words at all.
         if (lane == 0) {
             if (failed) st_dev(root + 16, 1ull);
-            if (__hip_atomic_fetch_add(g_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(g_tiles - 1u) &&
-                __hip_atomic_fetch_add(root, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n_groups - 1u))
-                last = 1;
+            const unsigned long long tg_old = __hip_atomic_fetch_add(g_ticket, 1ull | (left_by_poison ? 1ull << 32 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned int)tg_old == g_tiles - 1u) {
+                const bool g_clean = (tg_old >> 32) != 0 || left_by_poison;
+                const unsigned long long tr_old = __hip_atomic_fetch_add(root, 1ull | (g_clean ? 1ull << 32 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)tr_old == n_groups - 1u) last = ((unsigned int)(tr_old >> 32) + (g_clean ? 1u : 0u) == n_groups) ? 1 : 2;   // 2: look for unclaimed items
+            }
         }
     }
     if (dbg && lane == 0) {
         unsigned long long* d = dbg + (1 << 19) + (size_t)(blockIdx.x * 4 + wave) * 8;
         d[0] = rt_start; d[1] = rt_tile; d[2] = rt_acc; d[3] = rt_loop; d[4] = n_items; d[5] = n_polls | ((unsigned long long)n_casfail << 32); d[6] = S.dbg_pairs | ((unsigned long long)S.dbg_passes << 40) | ((unsigned long long)__popcll(um) << 48); d[7] = __builtin_amdgcn_s_memrealtime();
     }
-    if (!__builtin_amdgcn_readfirstlane(last)) return;
-    // ---- last wave of the launch.  Normally every item has been claimed and served by now.  But nobody is OBLIGED to wait for work
-    // (a wave that cannot see every tile of the launch started leaves when it finds nothing), so items reserved after the last wave of
-    // their group left may still sit in the queue: serve them here, then clean the queue words for the next launch.
-    {
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    // ---- last wave of the launch.  Nobody is OBLIGED to wait for work (a wave that cannot see every tile of the launch started
+    // leaves when it finds nothing), so items reserved after the last wave of their group left may still sit in the queue: unless
+    // every group reported a wave that left by the poison, look for them and serve them here.  Then clean the queue words.
+    if (last == 2) {
         unsigned long long qw = 0;
         if (lane < (int)n_groups) qw = ld_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane);
         const unsigned int r_l = (unsigned int)(qw & Q_MASK), c_l = (unsigned int)((qw >> Q_BITS) & Q_MASK);
@@ -1525,14 +1534,14 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
                 pass_serve_item(gv, L, lane, w, max_d2, A, res_pos, dbg, 59999u, t_start);
             }
         }
-        if (lane < (int)n_groups) {
-            st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane, 0ull);
-            st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 16, 0ull);
-            st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 17, 0ull);
-        }
-        if (lane == 0) st_dev(root, 0ull);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the leftovers' atomics, if any)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the leftovers' atomics
     }
+    if (lane < (int)n_groups) {   // (stores: nobody waits for them)
+        st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane, 0ull);
+        st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 16, 0ull);
+        st_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane + 17, 0ull);
+    }
+    if (lane == 0) st_dev(root, 0ull);
     pass_finish(gv, L, lane, A, root, dbg);
 }
 
