@@ -1346,6 +1346,7 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     const unsigned long long um = __ballot(unres);
     unsigned int mine = 0;     // slot index this wave owns (claimed below, or in the loop)
     bool have_claim = false;
+    unsigned long long own = 0;   // reply of the add that reports the tile done (used after the moments: its round trip hides behind them)
     unsigned long long* const root = A.sync + (size_t)PASS_SYNC_STRIDE * PASS_GROUPS;
     {
         // The k-th open query of the tile reserves a slot in group (g + k) mod groups, all of them by ONE vector atomic -- a tile in a
@@ -1358,7 +1359,6 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         unsigned long long slot_w = 0;
         if (unres) slot_w = __hip_atomic_fetch_add(A.sync + (size_t)PASS_SYNC_STRIDE * tg, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("" :: "v"(slot_w) : "memory");   // replies first
-        unsigned long long own = 0;
         if (lane == 0)
             own = __hip_atomic_fetch_add(g_q, (1ull << (2 * Q_BITS)) | (all_started ? 1ull << Q_BITS : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (unres) {
@@ -1370,6 +1370,34 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
             st_dev(it + 2, S.az == S.az ? (unsigned long long)__double_as_longlong(S.az) : 0x7ff8000000000000ull);
             st_dev(it + 3, (unsigned long long)(unsigned int)S.qi | ((unsigned long long)__float_as_uint(cand ? S.bound2 : INFINITY) << 32));
         }
+    }
+    // ---- moments of the proven queries.  Every correspondence is rounded to the fixed-point grid ONCE, by itself; from there on
+    // only integers are added (here through the wave's LDS slice, then by the atomics): the totals do not depend on how queries
+    // are grouped into tiles or queue items, or on any order.
+    {
+        double m[PCR_NMOM];
+#pragma unroll
+        for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+        if (proven) {
+            if (nb_known) { nb.x = P.seed_b.x; nb.y = P.seed_b.y; nb.z = P.seed_b.z; }
+            else A.prev_xyz[S.qi] = wt_xyz{nb.x, nb.y, nb.z};   // seed of the next pass's tile
+            moments_add(m, gv.origin, S.ax, S.ay, S.az, nb, max_d2, 1);
+        }
+        if (lane < WT_Q) {
+#pragma unroll
+            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xll[lane * (PCR_NMOM - 1) + k] = to_fixed(m[k], A.scale);
+        }
+        wave_sync();
+        long long tot = 0;
+        if (lane < PCR_NMOM - 1) {
+#pragma unroll 8
+            for (int j = 0; j < WT_Q; ++j) tot += L->xll[j * (PCR_NMOM - 1) + lane];
+        }
+        acc_fixed_add_ll(A.acc, tile, lane, tot);
+        wave_sync();
+    }
+    // ---- the reply of the done-add: this wave's first slot, and whether it was the last tile of its group
+    {
         {
             const unsigned int o_lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)own), o_hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(own >> 32));
             own = ((unsigned long long)o_hi << 32) | o_lo;
@@ -1397,31 +1425,6 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
                 }
             }
         }
-    }
-    // ---- moments of the proven queries.  Every correspondence is rounded to the fixed-point grid ONCE, by itself; from there on
-    // only integers are added (here through the wave's LDS slice, then by the atomics): the totals do not depend on how queries
-    // are grouped into tiles or queue items, or on any order.
-    {
-        double m[PCR_NMOM];
-#pragma unroll
-        for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
-        if (proven) {
-            if (nb_known) { nb.x = P.seed_b.x; nb.y = P.seed_b.y; nb.z = P.seed_b.z; }
-            else A.prev_xyz[S.qi] = wt_xyz{nb.x, nb.y, nb.z};   // seed of the next pass's tile
-            moments_add(m, gv.origin, S.ax, S.ay, S.az, nb, max_d2, 1);
-        }
-        if (lane < WT_Q) {
-#pragma unroll
-            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xll[lane * (PCR_NMOM - 1) + k] = to_fixed(m[k], A.scale);
-        }
-        wave_sync();
-        long long tot = 0;
-        if (lane < PCR_NMOM - 1) {
-#pragma unroll 8
-            for (int j = 0; j < WT_Q; ++j) tot += L->xll[j * (PCR_NMOM - 1) + lane];
-        }
-        acc_fixed_add_ll(A.acc, tile, lane, tot);
-        wave_sync();
     }
     if (dbg) rt_acc = __builtin_amdgcn_s_memrealtime();
     if (dbg && lane == 0) {   // per-block counters of scripts/wt_stamps.py and bench.py (filter pairs, passes, open queries, cycles)
