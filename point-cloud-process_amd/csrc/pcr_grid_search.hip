@@ -1949,6 +1949,36 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
 // order, solves the 3x3 Procrustes step, tests convergence and writes the next increment into the device state, which
 // the next tile kernel reads.  The host enqueues a CHUNK of passes, then copies the 4.5-KB state back once; passes
 // enqueued behind a stop return at their first instruction.
+// Everything the one-launch pass wants initialised at the start of an ICP call, in ONE launch (three API calls -- state upload, two
+// memsets -- cost a registration of one iteration, as in the batch, 10-15 us): accumulators and queue words zero, item slots all-ones,
+// the loop state built from T0 (what pcr_grid_icp_loop writes into the host copy).
+struct pass_T0 { double v[16]; };
+__global__ void __launch_bounds__(256)
+pass_init_kernel(unsigned long long* __restrict__ zero_p, unsigned int zero_n, unsigned long long* __restrict__ ones_p, unsigned long long ones_n,
+                 pcr_icp_dev_state* __restrict__ st, pass_T0 T0) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < ones_n; i += stride) ones_p[i] = ~0ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += stride) zero_p[i] = 0ull;
+    if (blockIdx.x != 0) return;
+    static_assert(sizeof(pcr_icp_dev_state) % 8 == 0, "state in 8-byte words");
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(st);
+    for (unsigned int i = threadIdx.x; i < sizeof(pcr_icp_dev_state) / 8; i += blockDim.x) w[i] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                st->x.r[3 * i + j] = T0.v[4 * i + j];
+                st->R_last[3 * i + j] = T0.v[4 * i + j];
+            }
+            st->x.t[i] = T0.v[4 * i + 3];
+            st->t_last[i] = T0.v[4 * i + 3];
+        }
+        for (int i = 0; i < 16; ++i) st->T_total[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 9; ++i) st->V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        st->first = 1;
+    }
+}
+
 // ICP loops of this process in flight on the device (any context)
 static std::atomic<int> g_loops_in_flight{0};
 struct loop_guard {
@@ -2027,9 +2057,16 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     la.max_iter = params->max_iter; la.min_iter = params->min_iter;
     la.compat = params->mode == PCR_ICP_COMPAT_MAIN; la.r_metric = params->r_metric;
     la.r_thres = params->r_thres; la.t_thres = params->t_thres;
-    hipError_t e = hipMemcpyAsync(d_st, h_st, sizeof(*h_st), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && fused) e = hipMemsetAsync(sc.acc, 0, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS), ctx->stream);
-    if (e == hipSuccess && fused) e = hipMemsetAsync(sc.items, 0xff, 32 * (size_t)PASS_GROUPS * pa.cap, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (fused) {
+        pass_T0 t0;
+        for (int i = 0; i < 16; ++i) t0.v[i] = T0[i];
+        const unsigned long long ones_n = 4ull * PASS_GROUPS * pa.cap;
+        const int ib = (int)((ones_n + 256 * 8 - 1) / (256 * 8));
+        hipLaunchKernelGGL(pass_init_kernel, dim3(ib < 1 ? 1 : (ib > 1024 ? 1024 : ib)), dim3(256), 0, ctx->stream, sc.acc,
+                           (unsigned int)(ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS), sc.items, ones_n, d_st, t0);
+        e = hipGetLastError();
+    } else e = hipMemcpyAsync(d_st, h_st, sizeof(*h_st), hipMemcpyHostToDevice, ctx->stream);
     pa.st = d_st;
     pa.la = la;
     pcr_xform xi;
