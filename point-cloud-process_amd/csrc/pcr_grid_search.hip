@@ -1979,17 +1979,17 @@ pass_init_kernel(unsigned long long* __restrict__ zero_p, unsigned int zero_n, u
     }
 }
 
-// ICP loops of this process in flight on the device (any context)
-static std::atomic<int> g_loops_in_flight{0};
+// ICP loops of this process in flight per device (any context)
+static std::atomic<int> g_loops_in_flight[64];   // per device ordinal (zero-initialised)
 struct loop_guard {
-    int n;
-    loop_guard() : n(g_loops_in_flight.fetch_add(1) + 1) {}
-    ~loop_guard() { g_loops_in_flight.fetch_sub(1); }
+    std::atomic<int>& n;
+    explicit loop_guard(int device) : n(g_loops_in_flight[(unsigned int)device % 64u]) { n.fetch_add(1); }
+    ~loop_guard() { n.fetch_sub(1); }
 };
 
 int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_icp_params* params, const double T0[16],
                       pcr_icp_result* res) {
-    const loop_guard in_flight;
+    const loop_guard in_flight(ctx->device);
     const char* const wait_s = getenv("PCR_PASS_INLINE");   // read per call: the tests switch it
     const int wait_env = wait_s ? atoi(wait_s) : -1;   // 0 / 1 force a variant; default: inline when alone on the device
     const bool gated = (params->max_d2 > 0) && std::isfinite(params->max_d2);
@@ -2087,7 +2087,7 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             // launch of several generations most waves may not wait for work (the later tiles need their slots), and the queue
             // would be served by the last generation alone (1 M points: 2.4 ms per pass against 0.32 ms for two launches)
             const bool one_generation = (nq + WT_Q - 1) / WT_Q <= 16ll * ctx->cu_count;
-            const int inline_queue = wait_env >= 0 ? wait_env : ((one_generation && !ctx->shared_device && g_loops_in_flight.load(std::memory_order_relaxed) == 1) ? 1 : 0);
+            const int inline_queue = wait_env >= 0 ? wait_env : ((one_generation && !ctx->shared_device && in_flight.n.load(std::memory_order_relaxed) == 1) ? 1 : 0);
             if (fused) {
                 if (ctx->profile) pcr_prof_mark(ctx, 0);
                 if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)((nq + 63) / 64)), ctx->stream);
