@@ -57,12 +57,13 @@ __device__ static inline void group_best(double& bd2, long long& bid, unsigned i
     }
 }
 
+struct wt_xyz;   // (the 24 coordinate bytes of a record, defined below)
 __device__ static inline void scan_range(const pcr_pt* __restrict__ pts, unsigned int s, unsigned int e, unsigned int step, double ax,
-                                         double ay, double az, double& bd2, long long& bid, unsigned int& bpos) {
+                                         double ay, double az, double& bd2, long long& bid, unsigned int& bpos, double* bw) {
     for (unsigned int j = s; j < e; j += step) {
         const pcr_pt b = pts[j];
         const double d2 = dist2(ax, ay, az, b);
-        if (better(d2, b.id, bd2, bid)) { bd2 = d2; bid = b.id; bpos = j; }
+        if (better(d2, b.id, bd2, bid)) { bd2 = d2; bid = b.id; bpos = j; bw[0] = b.x; bw[1] = b.y; bw[2] = b.z; }
     }
 }
 
@@ -828,7 +829,7 @@ struct hard_lds {
 // trip instead of one per cell).  Cells that are still big are pushed for a later split, nearest last.
 __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L, int& sp, int lane, bool valid, unsigned int s, unsigned int e,
                                             unsigned int X, unsigned int Y, unsigned int Z, int lvl, double bdist, double ax, double ay,
-                                            double az, double& bd2, long long& bid, unsigned int& bpos, double& bound2, unsigned int& n_pts) {
+                                            double az, double& bd2, long long& bid, unsigned int& bpos, double& bound2, unsigned int& n_pts, double* bw) {
     const unsigned int cnt = e - s;
     const bool small = valid && (lvl == 0 || cnt <= HARD_SCAN_T);
     const unsigned long long m_small = __ballot(small);
@@ -869,11 +870,11 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
             if (ok[1]) b1 = gv.pts[jj[1]];
             if (ok[0]) {
                 const double d2 = dist2(ax, ay, az, b0);
-                if (better(d2, b0.id, bd2, bid)) { bd2 = d2; bid = b0.id; bpos = jj[0]; }
+                if (better(d2, b0.id, bd2, bid)) { bd2 = d2; bid = b0.id; bpos = jj[0]; bw[0] = b0.x; bw[1] = b0.y; bw[2] = b0.z; }
             }
             if (ok[1]) {
                 const double d2 = dist2(ax, ay, az, b1);
-                if (better(d2, b1.id, bd2, bid)) { bd2 = d2; bid = b1.id; bpos = jj[1]; }
+                if (better(d2, b1.id, bd2, bid)) { bd2 = d2; bid = b1.id; bpos = jj[1]; bw[0] = b1.x; bw[1] = b1.y; bw[2] = b1.z; }
             }
         }
         double m = bd2;
@@ -903,7 +904,7 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
             const int src = __ffsll((long long)mb) - 1;
             mb &= mb - 1;
             const unsigned int ss = __shfl(s, src, 64), ee = __shfl(e, src, 64);
-            scan_range(gv.pts, ss + lane, ee, 64, ax, ay, az, bd2, bid, bpos);
+            scan_range(gv.pts, ss + lane, ee, 64, ax, ay, az, bd2, bid, bpos, bw);
             n_pts += ee - ss;
         }
         double m = bd2;
@@ -918,7 +919,8 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
 // real point lies inside it.  On return every lane holds the same (bd2, bid, bpos); POS_NONE = nothing inside the bound.
 __device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard_lds* L, const int lane, const double ax, const double ay, const double az,
                                                    double bound2, bool have_cand, double& bd2, long long& bid, unsigned int& bpos,
-                                                   unsigned int& h_steps, unsigned int& h_pts, int& s_level0) {
+                                                   unsigned int& h_steps, unsigned int& h_pts, int& s_level0, double* win = nullptr) {
+    double bw[3] = {0.0, 0.0, 0.0};   // coordinates of this lane's best point (the scans have the record in hand: no gather for them later)
     const int top = gv.levels - 1;
     bd2 = DBL_MAX;
     bid = ID_NONE;
@@ -931,7 +933,7 @@ __device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard
         // nothing known yet (tile too large to stage): the query's own level-0 cell gives a first bound
         unsigned int s, e;
         if (lookup_cell(gv.table[0], gv.mask[0], (unsigned int)cx, (unsigned int)cy, (unsigned int)cz, &s, &e)) {
-            scan_range(gv.pts, s + lane, e, 64, ax, ay, az, bd2, bid, bpos);
+            scan_range(gv.pts, s + lane, e, 64, ax, ay, az, bd2, bid, bpos, bw);
             bound2 = fmin(bound2, wave_min(bd2));
         }
     }
@@ -966,7 +968,7 @@ __device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard
             valid = bdist <= bound2 && lookup_cell(gv.table[lvl], gv.mask[lvl], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &s, &e);
         }
         hard_disperse(gv, L, sp, lane, valid, s, e, (unsigned int)X, (unsigned int)Y, (unsigned int)Z, lvl, bdist, ax, ay, az, bd2, bid, bpos,
-                      bound2, h_pts);
+                      bound2, h_pts, bw);
         ++h_steps;
         while (sp > 0) {
             --sp;
@@ -979,7 +981,7 @@ __device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard
             const double cdist = box_dist2(gv, cl, ecell * 0.25, CX, CY, CZ, ax, ay, az);
             unsigned int cs = 0, ce = 0;
             const bool cvalid = cdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], CX, CY, CZ, &cs, &ce);
-            hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+            hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts, bw);
             ++h_steps;
         }
         const double safe = cell * (1.0 - 1e-9);
@@ -999,7 +1001,7 @@ __device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard
             bdist = box_dist2(gv, top, cell, X, Y, Z, ax, ay, az);
             valid = bdist <= bound2 && lookup_cell(gv.table[top], gv.mask[top], X, Y, Z, &s, &e);
         }
-        hard_disperse(gv, L, sp, lane, valid, s, e, X, Y, Z, top, bdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+        hard_disperse(gv, L, sp, lane, valid, s, e, X, Y, Z, top, bdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts, bw);
         ++h_steps;
         while (sp > 0) {
             --sp;
@@ -1011,16 +1013,24 @@ __device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard
             const double cdist = box_dist2(gv, cl, ecell * 0.25, CX, CY, CZ, ax, ay, az);
             unsigned int cs = 0, ce = 0;
             const bool cvalid = cdist <= bound2 && lookup_cell(gv.table[cl], gv.mask[cl], CX, CY, CZ, &cs, &ce);
-            hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts);
+            hard_disperse(gv, L, sp, lane, cvalid, cs, ce, CX, CY, CZ, cl, cdist, ax, ay, az, bd2, bid, bpos, bound2, h_pts, bw);
             ++h_steps;
         }
     }
+    const unsigned int own_pos = bpos;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const double od2 = __shfl_xor(bd2, off, 64);
         const long long oid = __shfl_xor(bid, off, 64);
         const unsigned int opos = __shfl_xor(bpos, off, 64);
         if (better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; bpos = opos; }
+    }
+    if (win) {   // the lane that scanned the winner hands its coordinates over through LDS (every point is scanned by one lane)
+        double* xw = reinterpret_cast<double*>(L->fl_off);
+        wave_sync();
+        if (bpos != POS_NONE && own_pos == bpos) { xw[0] = bw[0]; xw[1] = bw[1]; xw[2] = bw[2]; }
+        wave_sync();
+        win[0] = xw[0]; win[1] = xw[1]; win[2] = xw[2];
     }
 }
 
@@ -1199,11 +1209,13 @@ __device__ __forceinline__ static void pass_serve_item(const pcr_grid_view& gv, 
     long long bid;
     unsigned int bpos;
     const bool have_cand = cand_b2 < INFINITY;
-    hard_search(gv, &L->h, lane, ax, ay, az, have_cand ? fmin((double)cand_b2, max_d2) : max_d2, have_cand, bd2, bid, bpos, h_steps, h_pts, s_level0);
+    double win[3];
+    hard_search(gv, &L->h, lane, ax, ay, az, have_cand ? fmin((double)cand_b2, max_d2) : max_d2, have_cand, bd2, bid, bpos, h_steps, h_pts, s_level0, win);
     wave_sync();
     if (bpos != POS_NONE) {   // wave-uniform: after the merge every lane holds the same result
         if (lane == 0) {
-            const pcr_pt b = as_global(gv.pts)[bpos];
+            pcr_pt b;   // (the descent had the winner's record in hand: no gather)
+            b.x = win[0]; b.y = win[1]; b.z = win[2]; b.id = 0;
             A.prev_xyz[qi] = wt_xyz{b.x, b.y, b.z};
             double m[PCR_NMOM];
 #pragma unroll
