@@ -257,18 +257,27 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
                 unsigned int s = 0, e = 0;
                 if (!lookup_cell(gv.table[level], gv.mask[level], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &s, &e)) continue;
                 met += e - s;
-                for (unsigned int j = s; j < e; ++j) {
-                    const pcr_pt b = gv.pts[j];
-                    double d2 = dist2(ax, ay, az, b);
-                    long long id = b.id;
-                    if (!better(d2, id, bd[K - 1], bi[K - 1])) continue;
-                    // insertion into the sorted list with constant indices: the displaced element travels down
+                // four records per trip, requested together: one thread walking a cell record by record is a chain of dependent
+                // loads (2.2 ms for 120 000 queries, k = 8, at two waves per SIMD)
+                for (unsigned int j0 = s; j0 < e; j0 += 4) {
+                    pcr_pt rec[4];
 #pragma unroll
-                    for (int t = 0; t < K; ++t) {
-                        if (better(d2, id, bd[t], bi[t])) {
-                            const double td = bd[t]; const long long ti = bi[t];
-                            bd[t] = d2; bi[t] = id;
-                            d2 = td; id = ti;
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < e) rec[u] = gv.pts[j0 + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j0 + u >= e) break;
+                        double d2 = dist2(ax, ay, az, rec[u]);
+                        long long id = rec[u].id;
+                        if (!better(d2, id, bd[K - 1], bi[K - 1])) continue;
+                        // insertion into the sorted list with constant indices: the displaced element travels down
+#pragma unroll
+                        for (int t = 0; t < K; ++t) {
+                            if (better(d2, id, bd[t], bi[t])) {
+                                const double td = bd[t]; const long long ti = bi[t];
+                                bd[t] = d2; bi[t] = id;
+                                d2 = td; id = ti;
+                            }
                         }
                     }
                 }
