@@ -32,7 +32,15 @@ __device__ static inline void iss_visit_block(const pcr_grid_view& gv, double ax
             if (nx <= (unsigned int)PCR_COORD_MAX && ny <= (unsigned int)PCR_COORD_MAX && nz <= (unsigned int)PCR_COORD_MAX) {
                 unsigned int s, e;
                 if (lookup_cell(gv.table[0], gv.mask[0], nx, ny, nz, &s, &e))
-                    for (unsigned int j = s; j < e; ++j) f(gv.pts[j]);
+                    for (unsigned int j0 = s; j0 < e; j0 += 4) {   // four records per trip, requested together
+                        pcr_pt rec[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (j0 + u < e) rec[u] = gv.pts[j0 + u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (j0 + u < e) f(rec[u]);
+                    }
             }
         }
     }

@@ -112,19 +112,26 @@ normals_kernel(pcr_grid_view gv, long long n, double* __restrict__ normals /* by
         if (nx > (unsigned int)PCR_COORD_MAX || ny > (unsigned int)PCR_COORD_MAX || nz > (unsigned int)PCR_COORD_MAX) continue;
         unsigned int s, e;
         if (!lookup_cell(gv.table[0], gv.mask[0], nx, ny, nz, &s, &e)) continue;
-        for (unsigned int j = s; j < e; ++j) {
-            const pcr_pt b = gv.pts[j];
-            double d2 = dist2(p.x, p.y, p.z, b);
-            long long id = b.id;
-            unsigned int pos = j;
-            if (!better(d2, id, bd[K - 1], bi[K - 1])) continue;
-            // insertion into the sorted top-K (registers, fully unrolled bubble)
+        for (unsigned int j0 = s; j0 < e; j0 += 4) {   // four records per trip, requested together
+            pcr_pt rec[4];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (better(d2, id, bd[k], bi[k])) {
-                    const double td = bd[k]; const long long ti = bi[k]; const unsigned int tp = bp[k];
-                    bd[k] = d2; bi[k] = id; bp[k] = pos;
-                    d2 = td; id = ti; pos = tp;
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < e) rec[u] = gv.pts[j0 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u >= e) break;
+                double d2 = dist2(p.x, p.y, p.z, rec[u]);
+                long long id = rec[u].id;
+                unsigned int pos = j0 + u;
+                if (!better(d2, id, bd[K - 1], bi[K - 1])) continue;
+                // insertion into the sorted top-K (registers, fully unrolled bubble)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (better(d2, id, bd[k], bi[k])) {
+                        const double td = bd[k]; const long long ti = bi[k]; const unsigned int tp = bp[k];
+                        bd[k] = d2; bi[k] = id; bp[k] = pos;
+                        d2 = td; id = ti; pos = tp;
+                    }
                 }
             }
         }
