@@ -93,6 +93,41 @@ __device__ static inline bool lookup_cell(const pcr_cell_slot* __restrict__ tab,
     return false;
 }
 
+// Three cells (x - 1, x, x + 1; same y, z) at once: the twelve loads of their three buckets are in flight together (a thread
+// that walks the 27 cells around a point one lookup after the other pays 27 dependent round trips).  found bit i = cell x - 1 + i.
+__device__ static inline unsigned int lookup_cell3(const pcr_cell_slot* __restrict__ tab, unsigned int mask, unsigned int x, unsigned int y,
+                                                   unsigned int z, unsigned int lim, unsigned int s[3], unsigned int e[3]) {
+    const pcr_gu4p base = (pcr_gu4p)(const void*)tab;
+    pcr_u4 v[3][4];
+    bool in[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const unsigned int xi = x + (unsigned int)i - 1u;   // x = 0: wraps, caught by the range test
+        in[i] = xi <= lim;
+        const pcr_gu4p bk = base + (size_t)(cell_hash(in[i] ? xi : x, y, z) & mask) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[i][k] = bk[k];
+    }
+    asm volatile("" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]));
+    asm volatile("" : "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]));
+    asm volatile("" : "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]));
+    unsigned int found = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (!in[i]) continue;
+        const unsigned int xi = x + (unsigned int)i - 1u;
+        const unsigned long long key = cell_pack(xi, y, z);
+        bool hit = false, settled = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!hit && u4_key(v[i][k]) == key) { s[i] = v[i][k].z; e[i] = v[i][k].w; hit = true; }
+        settled = hit || u4_key(v[i][3]) == PCR_EMPTY_KEY;   // a free last slot: the bucket never overflowed
+        if (!settled) hit = lookup_cell(tab, mask, xi, y, z, &s[i], &e[i]);   // (rare) follow the probe chain
+        if (hit) found |= 1u << i;
+    }
+    return found;
+}
+
 // 2x2x2-block lookup: one 32-byte read in almost every case (both halves requested together, see lookup_cell)
 __device__ static inline bool lookup_block(const pcr_block_slot* __restrict__ tab, unsigned int mask, unsigned int bx, unsigned int by,
                                            unsigned int bz, pcr_block_slot* out) {

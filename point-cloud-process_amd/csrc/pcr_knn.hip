@@ -228,6 +228,9 @@ radius_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq
 // tried first, then level 1 (cells 4x wider), then -- in sparse surroundings only -- levels 2 and 3.  Queries it cannot prove (sparse surroundings, fewer than k points in
 // reach, coordinates outside the grid) go to a list for the wave-per-query descent above.  On a KITTI scan the block
 // scan settles > 95 % of the queries at ~1/40 of the descent's cost per query.
+#ifndef PCR_KNN_LV
+#define PCR_KNN_LV 3
+#endif
 template <int K>
 __global__ void __launch_bounds__(256)
 knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq, int k, int* __restrict__ idx_out,
@@ -243,7 +246,7 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
         const int cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
         const int cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
         // levels 0, 1 and -- only where the surroundings are sparse (few points met one level down) -- 2 and 3
-        const int max_level = gv.levels - 1 < 3 ? gv.levels - 1 : 3;
+        const int max_level = gv.levels - 1 < PCR_KNN_LV ? gv.levels - 1 : PCR_KNN_LV;
         unsigned int met = 0;
         for (int level = 0; level <= max_level && !clamped && !proven && (level < 2 || met <= 192u); ++level) {
             met = 0;
@@ -251,11 +254,15 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
             for (int j = 0; j < K; ++j) { bd[j] = DBL_MAX; bi[j] = 0x7fffffffffffffffll; }
             const int X0 = cx >> (2 * level), Y0 = cy >> (2 * level), Z0 = cz >> (2 * level);
             const int lim = (int)(PCR_COORD_MAX >> (2 * level));
-            for (int c = 0; c < 27; ++c) {
-                const int X = X0 + (c % 3) - 1, Y = Y0 + ((c / 3) % 3) - 1, Z = Z0 + (c / 9) - 1;
-                if (X < 0 || Y < 0 || Z < 0 || X > lim || Y > lim || Z > lim) continue;
-                unsigned int s = 0, e = 0;
-                if (!lookup_cell(gv.table[level], gv.mask[level], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &s, &e)) continue;
+            for (int c3 = 0; c3 < 9; ++c3) {
+              const int Y = Y0 + (c3 % 3) - 1, Z = Z0 + (c3 / 3) - 1;
+              if (Y < 0 || Z < 0 || Y > lim || Z > lim) continue;
+              unsigned int s3[3] = {0, 0, 0}, e3[3] = {0, 0, 0};
+              const unsigned int found = lookup_cell3(gv.table[level], gv.mask[level], (unsigned int)X0, (unsigned int)Y, (unsigned int)Z, (unsigned int)lim, s3, e3);
+#pragma unroll
+              for (int cx3 = 0; cx3 < 3; ++cx3) {
+                if (!((found >> cx3) & 1u)) continue;
+                const unsigned int s = s3[cx3], e = e3[cx3];
                 met += e - s;
                 // four records per trip, requested together: one thread walking a cell record by record is a chain of dependent
                 // loads (2.2 ms for 120 000 queries, k = 8, at two waves per SIMD)
@@ -281,6 +288,7 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
                         }
                     }
                 }
+              }
             }
             // radius the block certainly covers: distance to its nearest face
             const double cell = gv.cell0 * (double)(1ll << (2 * level));
