@@ -165,8 +165,9 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
     hipLaunchKernelGGL(iss_cov_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, radius, (const int*)d_counts, d_lam, gamma21,
                        gamma32, d_cand, d_cand_count);
     PCR_HIP(ctx, hipGetLastError());
-    PCR_HIP(ctx, hipMemcpyAsync(lambdas_out, d_lam, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
-    if (counts_out) PCR_HIP(ctx, hipMemcpyAsync(counts_out, d_counts, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    // (24 MB + 4 MB at 1 M points: through the pinned double buffer, a pageable copy runs at ~4.5 GB/s)
+    if ((rc = pcr_d2h_staged(ctx, lambdas_out, d_lam, sizeof(double) * 3 * (size_t)n))) return rc;
+    if (counts_out && (rc = pcr_d2h_staged(ctx, counts_out, d_counts, sizeof(int) * (size_t)n))) return rc;
     unsigned int n_cand = 0;
     if (want_kp) PCR_HIP(ctx, hipMemcpyAsync(&n_cand, d_cand_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
