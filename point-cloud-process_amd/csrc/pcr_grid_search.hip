@@ -1333,9 +1333,9 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         if (lane == 0) A.tile_cost[tile] = (S.staged < 0xffffu ? S.staged : 0xffffu) | (n_open << 16);
     }
     if (dbg) rt_tile = __builtin_amdgcn_s_memrealtime();
-    // ---- leave the tile stage.  Requested together: the target records of the proven queries (for the moments) and the
-    // group's started count; then ONE returning add reserves the slots of the open queries, reports the tile done and --
-    // when the whole group has started, so that waiting is allowed -- already claims this wave's first slot to serve.
+    // ---- leave the tile stage.  First the target records of the proven queries are requested (for the moments; a neighbour that did
+    // not change came with the seed), then the open queries reserve their queue slots, then the tile reports done -- and, when the
+    // whole launch has started, so that waiting is allowed, claims this wave's first slot to serve with the same add.
     const bool proven = lane < WT_Q && S.won != POS_NONE;
     pcr_pt nb;
     nb.x = nb.y = nb.z = 0.0; nb.id = 0;
