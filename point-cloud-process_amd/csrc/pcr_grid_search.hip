@@ -446,6 +446,13 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
         wave_sync();
         WT_STAMP(3);
         staged += total;
+        // (one-launch ICP pass: a tile that turns out heavy takes issue priority for the rest of its stage -- the caller already gave
+        // it what last pass's load suggested; this also covers the unseeded first pass, which has no history: 92 -> 87 us)
+        if (probe_groups) {
+            if (staged > 3 * WT_PR) __builtin_amdgcn_s_setprio(3);
+            else if (staged > 2 * WT_PR) __builtin_amdgcn_s_setprio(2);
+            else if (staged > WT_PR) __builtin_amdgcn_s_setprio(1);
+        }
         if (total > pcap) { if (part) WT_WHY(2); continue; }   // too many points to stage around this tile: a later pass has tighter balls, or the hard stage takes over
         if (dbg) dbg_pairs += (unsigned long long)total * (unsigned long long)__popcll(__ballot(part && lane < WT_Q));
         const float cellLf = (float)gv.cell0 * (float)(1 << (2 * level));
