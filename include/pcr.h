@@ -271,9 +271,10 @@ PCR_API int pcr_dbscan(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int 
 PCR_API int pcr_timer_start(pcr_ctx* ctx);
 PCR_API int pcr_timer_stop_ms(pcr_ctx* ctx, double* ms_out);
 /* Per-kernel HIP-event profile of the ICP pass (adds one event sync per pass while on).
- * slots: 0 = wave-tile stage (grid) / MFMA sweep (brute), 1 = hard stage fused with the accumulation and the Procrustes
- *        step (grid; ungated runs: hard stage only) / merge + exact fallback (brute), 2 = separate accumulate kernel
- *        (grid, ungated runs only) / final (brute), 3 = reduce (brute).
+ * slots: 0 = the one-launch ICP pass (grid: tiles, work queue, moments, Procrustes step; in the two-launch variant and in
+ *        ungated runs: the tile launch) / MFMA sweep (brute), 1 = the drain launch of the two-launch variant (ungated runs:
+ *        hard stage) / merge + exact fallback (brute), 2 = separate accumulate kernel (grid, ungated runs only) / final
+ *        (brute), 3 = reduce (brute).
  * ms_out[4] = summed milliseconds (each slot includes the launch gap in front of it), *passes_out = passes profiled. */
 /* diagnostics: per-block {cycles, work} stamps of the last grid search stage kernels (PCR_DEBUG_STAMPS=1) */
 PCR_API int pcr_debug_read(pcr_ctx* ctx, uint64_t* out, int64_t n_words);
