@@ -1130,7 +1130,7 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
 //             while several ICP loops of the process are in flight; same results bit for bit.
 //   finish    vmcnt(0) (own atomics acknowledged), then a two-level ticket (one word per group, then a root).
 #ifndef PCR_ACC_SETS
-#define PCR_ACC_SETS 64
+#define PCR_ACC_SETS 32
 #endif
 constexpr int ACC_SETS = PCR_ACC_SETS;
 #ifndef PCR_PASS_GROUPS
