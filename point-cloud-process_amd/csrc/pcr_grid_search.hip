@@ -1099,8 +1099,9 @@ grid_hard_kernel(pcr_grid_view gv, const work_item* __restrict__ list, const uns
 // integer additions commute, so waves may add in any order -- device-scope atomics, no slabs -- and the totals are still
 // bitwise reproducible.  Every correspondence is rounded to 2^-F once, on its own (<= N * 2^-F / 2 on a sum bounded by N R^2:
 // < 1e-12 relative at 120 000 points, three orders below the parity bar), so the totals are also independent of how the
-// queries are grouped into tiles and queue items.  64 sets of 20 words:
-// 1024 sets made the finishing read 14 us slower, one set serialises the atomics at their L2 channel.
+// queries are grouped into tiles and queue items.  32 sets of 20 words
+// (measured per pass: 8 sets 53.5 us -- the atomics queue at their lines --, 16: 41.9, 32: 41.0, 64: 42.1, 128: 42.5, 1024: +14 us
+// for the finishing read).
 //
 // Everything waves tell each other INSIDE the launch goes through device-scope atomics (performed at the coherence
 // point: the L2 of another XCD never holds a stale copy) and never needs a fence (an agent-scope release is an L2
