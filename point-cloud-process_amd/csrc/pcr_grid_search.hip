@@ -1500,7 +1500,10 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
             if (poisoned || mk == 0xfull) break;
             if (spins >= PASS_SPIN_LIMIT) { failed = true; break; }
             ++n_polls;
-            __builtin_amdgcn_s_sleep(4);
+#ifndef PCR_SLOT_SLEEP
+#define PCR_SLOT_SLEEP 16   // (1 / 4 / 16 / 32 / 64 measured within noise of each other; fewer polls = less traffic)
+#endif
+            __builtin_amdgcn_s_sleep(PCR_SLOT_SLEEP);
         }
         if (failed) break;
         if (poisoned) { left_by_poison = true; break; }
