@@ -17,8 +17,13 @@ What is imported, and how:
     A 20-line stand-in provides those (float64, scipy cKDTree = exact NN); the
     loop, gating, Procrustes, convergence test and return value that get
     recorded are the reference's own code.
-  * Keypoint_detection_ISS/ISS.py has no functions (script body) and cannot be
-    imported; ISS parity is "unpinned by the reference" (DESIGN.md).
+  * Keypoint_detection_ISS/ISS.py has no functions (script body under __main__): it is
+    EXECUTED unmodified with runpy.run_path(..., run_name="__main__") from a temporary
+    working directory that holds a seeded modelnet40_normal_resampled/chair/chair_0001.txt
+    (ISS.py:31,35), with a no-op stand-in for open3d (used only for the viewer, ISS.py:78-84,
+    after the result exists).  Its globals -- points, cand_idx, lambda3_idx_sort, iss_idx --
+    are the fixture tests/golden/iss.npz.  The hyper-parameters are locals of the script
+    (ISS.py:20-27), so the CLOUD is scaled to the radius 0.5, not the other way round.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/ref_harness.py [--big]
 """
@@ -488,6 +493,80 @@ def gen_readers(syn):
         print("reader", k, out[k].shape, out[k].dtype)
     np.savez_compressed(os.path.join(GOLD, "readers.npz"), **out)
 
+# --------------------------------------------------------------------------
+# G10: ISS keypoints -- Keypoint_detection_ISS/ISS.py:17-75 run unmodified as a script
+# --------------------------------------------------------------------------
+def _install_viewer_stub():
+    """open3d is touched only after the result exists (ISS.py:78-84): a viewer that does nothing."""
+    class _Pcd:
+        points = None
+
+        def paint_uniform_color(self, c):
+            return self
+
+        def select_by_index(self, idx):
+            return _Pcd()
+
+    o3d = types.ModuleType("open3d")
+    for sub in ("geometry", "utility", "visualization"):
+        setattr(o3d, sub, types.ModuleType("open3d." + sub))
+        sys.modules["open3d." + sub] = getattr(o3d, sub)
+    o3d.geometry.PointCloud = _Pcd
+    o3d.utility.Vector3dVector = lambda a: a
+    o3d.visualization.draw_geometries = lambda geoms, *a, **k: None
+    sys.modules["open3d"] = o3d
+
+
+def gen_iss(syn):
+    import runpy
+    import tempfile
+
+    script = os.path.join(REF, "Keypoint_detection_ISS", "ISS.py")
+    rng = np.random.default_rng(101)
+    cases = {}
+    # (a) ModelNet40-like object scaled so that a 0.5 ball holds a few tens of points -> more than 21 keypoints, the
+    #     iss_count break of ISS.py:72-73 fires;  (b) a sparser, noisier one -> fewer candidates than the cap;
+    #     (c) 6 columns like the real files (x,y,z,nx,ny,nz): only [:, :3] is used (ISS.py:36,42)
+    obj = syn.object_cloud(4000, seed=21).astype(np.float64) * 5.0
+    cases["object"] = obj + rng.normal(0, 0.01, obj.shape)
+    sp = syn.object_cloud(700, seed=22).astype(np.float64) * 1.6
+    cases["sparse"] = sp + rng.normal(0, 0.03, sp.shape)
+    six = syn.object_cloud(2500, seed=23).astype(np.float64) * 4.0
+    cases["six"] = np.hstack([six + rng.normal(0, 0.02, six.shape), rng.normal(0, 1, six.shape)])
+    out = {}
+    saved_mods = {k: sys.modules.get(k) for k in ("open3d", "open3d.geometry", "open3d.utility", "open3d.visualization")}
+    cwd = os.getcwd()
+    try:
+        _install_viewer_stub()
+        for tag, pts in cases.items():
+            d = tempfile.mkdtemp()
+            os.makedirs(os.path.join(d, "modelnet40_normal_resampled", "chair"))
+            with open(os.path.join(d, "modelnet40_normal_resampled", "chair", "chair_0001.txt"), "w") as f:
+                for row in pts:
+                    f.write(",".join(repr(float(v)) for v in row) + "\n")   # repr round-trips binary64 exactly
+            os.chdir(d)
+            with contextlib.redirect_stdout(io.StringIO()) as so, contextlib.redirect_stderr(io.StringIO()):
+                g = runpy.run_path(script, run_name="__main__")
+            os.chdir(cwd)
+            assert np.array_equal(g["points"], pts)
+            srt = g["lambda3_idx_sort"]          # every candidate, lambda3 descending (ISS.py:59); lambda3_idx itself is eaten by the NMS
+            out[tag + "_points"] = g["points"]
+            out[tag + "_iss_idx"] = np.asarray(g["iss_idx"], dtype=np.int64)
+            out[tag + "_cand_idx"] = np.asarray(g["cand_idx"], dtype=np.int64)
+            out[tag + "_sorted_idx"] = np.asarray(list(srt.keys()), dtype=np.int64)
+            out[tag + "_sorted_lambda3"] = np.asarray(list(srt.values()), dtype=np.float64)
+            out[tag + "_printed"] = np.asarray(so.getvalue().strip())
+            out[tag + "_params"] = np.array([g["radius"], g["lambda21"], g["lambda32"], g["non_max_radius"], g["iss_count"]])
+            print("iss %-7s n=%d cols=%d candidates=%d keypoints=%d" % (tag, len(pts), pts.shape[1], len(g["cand_idx"]), len(g["iss_idx"])))
+    finally:
+        os.chdir(cwd)
+        for k, v in saved_mods.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    np.savez_compressed(os.path.join(GOLD, "iss.npz"), **out)
+
 
 def ev_tq(T):
     """t, q (w first) of a pose for the result files (same convention as main.py:170-174, via scipy)."""
@@ -522,6 +601,8 @@ def main():
         gen_dbscan(syn)
     if a.only in ("", "readers"):
         gen_readers(syn)
+    if a.only in ("", "iss"):
+        gen_iss(syn)
 
 
 if __name__ == "__main__":

@@ -116,9 +116,31 @@ def test_knn_batch_properties(pcp, oracle, syn):
     assert k == 1 and abs(dd[0] - oracle.dist2_direct(q[0], db[ii[0]])) < 1e-15
 
 
+def test_iss_matches_the_reference_script_golden(pcp, golden):
+    """tests/golden/iss.npz holds what Keypoint_detection_ISS/ISS.py:17-75 itself computed (run unmodified in the build
+    container, oracle/ref_harness.py gen_iss): the printed keypoint list, the candidates of the ratio tests and their
+    lambda3 in sorted order.  pcr_iss must give the same keypoints, the same candidate set and lambda3 to 1e-9."""
+    g = golden("iss.npz")
+    for tag in ("object", "sparse", "six"):
+        pts = g[f"{tag}_points"]
+        radius, l21, l32, nmr, cap = g[f"{tag}_params"]
+        kp, lam, counts = pcp.iss_keypoints(pts[:, :3], radius=radius, lambda21=l21, lambda32=l32, non_max_radius=nmr,
+                                            iss_count=int(cap), return_details=True)
+        assert kp == g[f"{tag}_iss_idx"].tolist(), tag
+        cand = np.nonzero((lam[:, 1] / lam[:, 0] < l21) & (lam[:, 2] / lam[:, 1] < l32))[0]
+        assert np.array_equal(cand, g[f"{tag}_cand_idx"]), tag
+        srt = g[f"{tag}_sorted_idx"]
+        assert np.allclose(lam[srt, 2], g[f"{tag}_sorted_lambda3"], rtol=1e-9, atol=0), tag
+        # the weights the script used are 1 / len(query_ball_point(pj, radius)) (ISS.py:49): counts are implied
+        from scipy.spatial import cKDTree
+        assert np.array_equal(counts, cKDTree(pts[:, :3]).query_ball_point(pts[:, :3], radius, return_length=True)), tag
+    # the defaults of the drop-in are the script's hyper-parameters (ISS.py:20-27)
+    assert pcp.iss_keypoints(g["sparse_points"]) == g["sparse_iss_idx"].tolist()
+
+
 def test_iss_matches_cpu_restatement(pcp, oracle, syn):
-    """ISS.py has no importable function and its input file is absent: parity is against the
-    line-by-line CPU restatement only ("parity unpinned" by the reference)."""
+    """A second size/radius against the CPU restatement (itself pinned to the reference script's output by
+    tests/test_oracle_golden.py::test_iss_oracle_matches_the_reference_script)."""
     pts = syn.object_cloud(6000, seed=2).astype(np.float64)
     kp, lam, counts = pcp.iss_keypoints(pts, radius=0.08, non_max_radius=0.08, iss_count=20, return_details=True)
     okp, olam, ocounts = oracle.iss_oracle(pts, radius=0.08, non_max_radius=0.08, iss_count=20)

@@ -199,3 +199,24 @@ def test_icp_compat_big_golden_matches_oracle(oracle):
         assert r["iters"] == int(g[f"{tag}_iters"][0]) and int(r["failed"]) == int(g[f"{tag}_failed"][0])
         assert np.linalg.norm(r["T"] - g[f"{tag}_T"]) < 1e-9
         assert np.abs(r["src_after"] - g[f"{tag}_src_after"]).max() < 1e-9
+
+
+def test_iss_oracle_matches_the_reference_script(oracle):
+    """Keypoint_detection_ISS/ISS.py:17-75 was EXECUTED unmodified (runpy, seeded input file, no-op viewer stub;
+    oracle/ref_harness.py gen_iss) -> tests/golden/iss.npz.  The restatement must give the script's keypoint list,
+    its candidate list (ISS.py:55-57, in point order) and the lambda3 of every candidate in the script's sorted
+    order (ISS.py:59; np.linalg.eig there, eigvalsh here: 1e-9 relative)."""
+    g = load_golden("iss.npz")
+    for tag in ("object", "sparse", "six"):
+        pts = g[f"{tag}_points"]
+        radius, l21, l32, nmr, cap = g[f"{tag}_params"]
+        assert (radius, l21, l32, nmr, cap) == (0.5, 0.5, 0.5, 0.5, 20)        # ISS.py:20-27
+        kp, lam, counts = oracle.iss_oracle(pts, radius, l21, l32, nmr, int(cap))
+        assert kp == g[f"{tag}_iss_idx"].tolist(), tag
+        assert str(g[f"{tag}_printed"]) == str(kp), tag                       # print(iss_idx), ISS.py:75
+        cand = np.nonzero((lam[:, 1] / lam[:, 0] < l21) & (lam[:, 2] / lam[:, 1] < l32))[0]
+        assert np.array_equal(cand, g[f"{tag}_cand_idx"]), tag
+        srt = g[f"{tag}_sorted_idx"]
+        assert np.allclose(lam[srt, 2], g[f"{tag}_sorted_lambda3"], rtol=1e-9, atol=0), tag
+        assert len(kp) <= int(cap) + 1
+    assert len(g["sparse_iss_idx"]) < 21 and len(g["object_iss_idx"]) == 21     # both sides of the ISS.py:72-73 break
