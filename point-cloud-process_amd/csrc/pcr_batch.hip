@@ -1,0 +1,730 @@
+// Fused batch of registrations: ONE launch per stage for all pairs of a sub-batch
+// (the loop over scan pairs of Registration/main.py:190-216; per pair it does what
+// pcr_cloud_upload_f32 x 2 -> pcr_index_build -> pcr_icp do, main.py:105-156).
+//
+//   host     every cloud's xyz columns are packed into one pinned buffer (12 B per point) while its bounding box is taken;
+//            grid parameters (cell, levels, Morton bits, fixed-point scale) per pair: the same functions the per-pair path uses
+//   H2D      one copy of the packed coordinates + one of the descriptors
+//   keys     (cloud id << mbits | Morton key of the cloud's own curve) for every point of every cloud: sources first, then
+//            targets, every cloud in a slot of whole 256-record blocks
+//   sort     ONE rocPRIM radix sort over mbits + log2(clouds) bits
+//   gather   sorted 32-B records {x, y, z (binary64), caller's row}
+//   grids    run starts of every level counted per (target, level) -> table capacities and pool offsets planned ON THE DEVICE
+//            (no size read-back) -> tables initialised -> cells and 2x2x2 blocks inserted, all targets per launch
+//   ICP      pcr_grid_batch_pass: tiles -> queue -> one Procrustes wave per pair, until every pair has stopped
+//   D2H      the loop states
+// About 15 launches + 3 x iterations per SUB-BATCH instead of ~46 launches and 3 synchronisations per PAIR.
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+#include "pcr_internal.h"
+#include "pcr_grid_dev.h"
+#include "pcr_icp_step.h"
+
+namespace {
+
+constexpr int SLOT = 256;                 // records per block of the set-up kernels; cloud slots are whole blocks
+constexpr unsigned int MIN_CAP = 256;     // smallest table of the pools: every block of 256 pool slots belongs to one table
+constexpr unsigned long long MORTON_BIAS3 = 7ull << 60;   // spread21(PCR_COORD_BIAS) on x, y and z
+
+struct batch_cloud {          // one per cloud of a sub-batch: sources [0, m), targets [m, 2m)
+    unsigned long long off;   // first record slot (multiple of SLOT)
+    long long n;
+    double lo[3];             // origin of the cloud's Morton curve (its bounding box's min corner)
+    double inv;               // 1 / cell of the curve
+};
+struct batch_target {         // per pair: what the plan kernel needs to write the pair's descriptor
+    double cell, hi[3];
+    int levels;
+    int pad;
+    double scale, inv_scale;
+};
+struct batch_plan {           // device: totals and prefix offsets written by the plan kernel
+    unsigned long long used_cells, used_blocks;   // slots of the two pools in use
+    unsigned int overflow;
+    unsigned int pad;
+};
+
+__device__ inline unsigned int next_pow2_dev(unsigned int v) {
+    return v <= 1 ? 1u : 1u << (32 - __clz((int)(v - 1)));
+}
+
+// cloud of a block of SLOT records: clouds' slots are whole blocks, so the answer is uniform over the block
+__device__ inline int cloud_of_block(const batch_cloud* __restrict__ cl, int n_clouds, unsigned long long first) {
+    __shared__ int s_c;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n_clouds - 1;   // last cloud with off <= first
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cl[mid].off <= first) lo = mid;
+            else hi = mid - 1;
+        }
+        s_c = lo;
+    }
+    __syncthreads();
+    return s_c;
+}
+
+__global__ void __launch_bounds__(SLOT)
+batch_keys_kernel(const float* __restrict__ xyz, const batch_cloud* __restrict__ cl, int n_clouds, int mbits, unsigned long long* __restrict__ keys,
+                  unsigned int* __restrict__ vals) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * SLOT + threadIdx.x;
+    const int c = cloud_of_block(cl, n_clouds, (unsigned long long)blockIdx.x * SLOT);
+    const batch_cloud C = cl[c];
+    const unsigned long long mask = (1ull << mbits) - 1ull;
+    unsigned long long k = mask;   // padding of the slot: behind every point of its cloud (the sort is stable)
+    if (i - C.off < (unsigned long long)C.n) {
+        const float* p = xyz + 3 * i;
+        bool clamped = false;
+        const unsigned long long cx = (unsigned long long)cell_coord((double)p[0], C.lo[0], C.inv, &clamped);
+        const unsigned long long cy = (unsigned long long)cell_coord((double)p[1], C.lo[1], C.inv, &clamped);
+        const unsigned long long cz = (unsigned long long)cell_coord((double)p[2], C.lo[2], C.inv, &clamped);
+        k = (spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2)) & mask;
+    }
+    keys[i] = ((unsigned long long)c << mbits) | k;
+    vals[i] = (unsigned int)i;
+}
+
+__global__ void __launch_bounds__(SLOT)
+batch_gather_kernel(const float* __restrict__ xyz, const unsigned int* __restrict__ perm, const batch_cloud* __restrict__ cl, int n_clouds,
+                    pcr_pt* __restrict__ out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * SLOT + threadIdx.x;
+    const int c = cloud_of_block(cl, n_clouds, (unsigned long long)blockIdx.x * SLOT);
+    const unsigned long long off = cl[c].off;
+    pcr_pt o;
+    o.x = o.y = o.z = 0.0; o.id = 0;
+    if (i - off < (unsigned long long)cl[c].n) {
+        const unsigned int src = perm[i];
+        const float* p = xyz + 3 * (unsigned long long)src;
+        o.x = (double)p[0];
+        o.y = (double)p[1];
+        o.z = (double)p[2];
+        o.id = (long long)(src - off);   // the caller's row
+    }
+    out[i] = o;
+}
+
+// run starts of every level, per target: counts[t][l] (one atomic per wave and level)
+__global__ void __launch_bounds__(SLOT)
+batch_count_kernel(const unsigned long long* __restrict__ keys, const batch_cloud* __restrict__ cl, int n_clouds, int m, const batch_target* __restrict__ tg,
+                   unsigned long long first_slot, int mbits, unsigned int* __restrict__ counts) {
+    const unsigned long long i = first_slot + (unsigned long long)blockIdx.x * SLOT + threadIdx.x;
+    const int c = cloud_of_block(cl, n_clouds, first_slot + (unsigned long long)blockIdx.x * SLOT);
+    const int t = c - m;
+    const unsigned long long li = i - cl[c].off;
+    const bool valid = li < (unsigned long long)cl[c].n;
+    const unsigned long long mask = (1ull << mbits) - 1ull;
+    const unsigned long long k = valid ? (keys[i] & mask) : 0ull, kp = (valid && li > 0) ? (keys[i - 1] & mask) : 0ull;
+    const int levels = tg[t].levels;
+    for (int l = 0; l < levels; ++l) {
+        const bool start = valid && (li == 0 || (k >> (6 * l)) != (kp >> (6 * l)));
+        const unsigned long long b = __ballot(start);
+        if (b && (threadIdx.x & 63) == 0) atomicAdd(&counts[t * PCR_MAX_LEVELS + l], (unsigned int)__popcll(b));
+    }
+}
+
+// ONE block: capacities of every (target, level) table from the counts, exclusive prefix over all of them = offsets into the two
+// pools, the pairs' descriptors (grid view, source slot, fixed-point scale), the tile -> pair map's inputs.
+__global__ void __launch_bounds__(256)
+batch_plan_kernel(const unsigned int* __restrict__ counts, const batch_cloud* __restrict__ cl, const batch_target* __restrict__ tg, int m,
+                  const pcr_pt* __restrict__ pts, pcr_cell_slot* __restrict__ cell_pool, unsigned long long cell_pool_slots,
+                  pcr_block_slot* __restrict__ block_pool, unsigned long long block_pool_slots, pcr_batch_pair* __restrict__ pairs,
+                  unsigned long long* __restrict__ cell_off, batch_plan* __restrict__ plan) {
+    __shared__ unsigned long long s_c[256], s_b[256];
+    const int n_e = m * PCR_MAX_LEVELS;
+    unsigned long long run_c = 0, run_b = 0;   // pool slots before this chunk of 256 entries
+    for (int base = 0; base < n_e; base += 256) {
+        const int e = base + (int)threadIdx.x;
+        unsigned int cap = 0, bcap = 0;
+        if (e < n_e) {
+            const int t = e / PCR_MAX_LEVELS, l = e % PCR_MAX_LEVELS;
+            if (l < tg[t].levels) {
+                const unsigned int cnt = counts[e];
+                cap = next_pow2_dev(cnt * 4 + 4);    // load factor <= 0.25 (pcr_grid_build)
+                if (cap < MIN_CAP) cap = MIN_CAP;
+                bcap = next_pow2_dev(cnt * 2 + 4);
+                if (bcap < MIN_CAP) bcap = MIN_CAP;
+            }
+        }
+        s_c[threadIdx.x] = cap;
+        s_b[threadIdx.x] = bcap;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {   // inclusive scan
+            unsigned long long a = 0, b = 0;
+            if ((int)threadIdx.x >= d) { a = s_c[threadIdx.x - d]; b = s_b[threadIdx.x - d]; }
+            __syncthreads();
+            s_c[threadIdx.x] += a;
+            s_b[threadIdx.x] += b;
+            __syncthreads();
+        }
+        const unsigned long long oc = run_c + s_c[threadIdx.x] - cap, ob = run_b + s_b[threadIdx.x] - bcap;
+        if (e < n_e) {
+            const int t = e / PCR_MAX_LEVELS, l = e % PCR_MAX_LEVELS;
+            cell_off[e] = oc;
+            pcr_grid_view* gv = &pairs[t].gv;
+            gv->table[l] = cap ? cell_pool + oc : nullptr;
+            gv->mask[l] = cap ? cap / 4 - 1 : 0;
+            gv->btable[l] = bcap ? block_pool + ob : nullptr;
+            gv->bmask[l] = bcap ? bcap - 1 : 0;
+        }
+        run_c += s_c[255];
+        run_b += s_b[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cell_off[n_e] = run_c;
+        plan->used_cells = run_c;
+        plan->used_blocks = run_b;
+        plan->overflow = (run_c > cell_pool_slots || run_b > block_pool_slots) ? 1u : 0u;
+    }
+    for (int t = threadIdx.x; t < m; t += 256) {
+        const batch_cloud S = cl[t], T = cl[m + t];
+        pcr_grid_view* gv = &pairs[t].gv;
+        gv->pts = pts + T.off;
+        gv->n = T.n;
+        gv->levels = tg[t].levels;
+        gv->cell0 = tg[t].cell;
+        gv->inv_cell0 = T.inv;
+        for (int k = 0; k < 3; ++k) {
+            gv->lo[k] = T.lo[k];
+            gv->origin[k] = 0.5 * (T.lo[k] + tg[t].hi[k]);
+        }
+        pairs[t].q_off = S.off;
+        pairs[t].nq = S.n;
+        pairs[t].scale = tg[t].scale;
+        pairs[t].inv_scale = tg[t].inv_scale;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+batch_init_tables_kernel(pcr_cell_slot* __restrict__ cell_pool, pcr_block_slot* __restrict__ block_pool, const batch_plan* __restrict__ plan,
+                         const pcr_batch_pair* __restrict__ pairs, int m, unsigned int* __restrict__ tile_pair, unsigned int n_tiles) {
+    if (plan->overflow) return;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nc = plan->used_cells, nb = plan->used_blocks;
+    typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+    u2* cp = reinterpret_cast<u2*>(cell_pool);
+    for (unsigned long long i = t0; i < nc; i += stride) cp[i] = u2{~0ull, ~0ull};
+    u2* bp = reinterpret_cast<u2*>(block_pool);
+    for (unsigned long long i = t0; i < 2 * nb; i += stride)
+        bp[i] = (i & 1) ? u2{0ull, 0ull} : u2{PCR_EMPTY_KEY, 0x00000000ffffffffull};   // key | start = ~0, flags = 0 | cnt[8] = 0
+    // tile -> pair: the sources' slots are whole tiles, in pair order
+    for (unsigned long long tl = t0; tl < n_tiles; tl += stride) {
+        const unsigned long long rec = tl * 32ull;
+        int lo = 0, hi = m - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pairs[mid].q_off <= rec) lo = mid;
+            else hi = mid - 1;
+        }
+        tile_pair[tl] = (unsigned int)lo;
+    }
+}
+
+__device__ inline unsigned int slot_find_or_insert(pcr_cell_slot* tab, unsigned int mask, unsigned long long key, unsigned int h) {
+    unsigned int b = h & mask;
+    for (unsigned int probe = 0; probe <= mask; ++probe) {
+        for (unsigned int k = 0; k < 4; ++k) {
+            const unsigned int slot = b * 4 + k;
+            const unsigned long long old = atomicCAS(&tab[slot].key, PCR_EMPTY_KEY, key);
+            if (old == PCR_EMPTY_KEY || old == key) return slot;
+        }
+        b = (b + 1) & mask;
+    }
+    return 0xffffffffu;
+}
+
+__global__ void __launch_bounds__(SLOT)
+batch_insert_cells_kernel(const unsigned long long* __restrict__ keys, const batch_cloud* __restrict__ cl, int n_clouds, int m,
+                          const pcr_batch_pair* __restrict__ pairs, unsigned long long first_slot, int mbits, const batch_plan* __restrict__ plan) {
+    if (plan->overflow) return;
+    const unsigned long long i = first_slot + (unsigned long long)blockIdx.x * SLOT + threadIdx.x;
+    const int c = cloud_of_block(cl, n_clouds, first_slot + (unsigned long long)blockIdx.x * SLOT);
+    const int t = c - m;
+    const unsigned long long li = i - cl[c].off, n = (unsigned long long)cl[c].n;
+    if (li >= n) return;
+    const unsigned long long mask = (1ull << mbits) - 1ull;
+    const unsigned long long k = (keys[i] & mask) | MORTON_BIAS3;
+    const unsigned long long kp = li > 0 ? (keys[i - 1] & mask) | MORTON_BIAS3 : 0ull;
+    const unsigned long long kn = li + 1 < n ? (keys[i + 1] & mask) | MORTON_BIAS3 : 0ull;
+    const pcr_grid_view* gv = &pairs[t].gv;
+    const int levels = gv->levels;
+    for (int l = 0; l < levels; ++l) {
+        const unsigned long long ck = k >> (6 * l);
+        const bool start = (li == 0) || (ck != (kp >> (6 * l)));
+        const bool end = (li + 1 == n) || (ck != (kn >> (6 * l)));
+        if (start || end) {
+            const unsigned int X = compact21(ck), Y = compact21(ck >> 1), Z = compact21(ck >> 2);
+            pcr_cell_slot* tab = const_cast<pcr_cell_slot*>(gv->table[l]);
+            const unsigned int h = slot_find_or_insert(tab, gv->mask[l], cell_pack(X, Y, Z), cell_hash(X, Y, Z));
+            if (h != 0xffffffffu) {
+                if (start) tab[h].start = (unsigned int)li;
+                if (end) tab[h].end = (unsigned int)(li + 1);
+            }
+        }
+    }
+}
+
+// one thread per slot of the cell pool: an occupied cell registers itself in its 2x2x2 block
+__global__ void __launch_bounds__(256)
+batch_insert_blocks_kernel(const pcr_cell_slot* __restrict__ cell_pool, const unsigned long long* __restrict__ cell_off, int n_e,
+                           const pcr_batch_pair* __restrict__ pairs, const batch_plan* __restrict__ plan) {
+    if (plan->overflow) return;
+    __shared__ int s_e;
+    const unsigned long long nc = plan->used_cells;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * 256; base < nc; base += (unsigned long long)gridDim.x * 256) {
+        __syncthreads();
+        if (threadIdx.x == 0) {   // entry (target, level) of this block of 256 slots: tables are whole blocks
+            int lo = 0, hi = n_e - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (cell_off[mid] <= base) lo = mid;
+                else hi = mid - 1;
+            }
+            s_e = lo;
+        }
+        __syncthreads();
+        const int e = s_e, t = e / PCR_MAX_LEVELS, l = e % PCR_MAX_LEVELS;
+        const pcr_cell_slot c = cell_pool[base + threadIdx.x];
+        if (c.key == PCR_EMPTY_KEY) continue;
+        const pcr_grid_view* gv = &pairs[t].gv;
+        pcr_block_slot* bt = const_cast<pcr_block_slot*>(gv->btable[l]);
+        const unsigned int bmask = gv->bmask[l];
+        const unsigned int X = (unsigned int)(c.key & 0x1fffffull), Y = (unsigned int)((c.key >> 21) & 0x1fffffull), Z = (unsigned int)((c.key >> 42) & 0x1fffffull);
+        const unsigned int BX = X >> 1, BY = Y >> 1, BZ = Z >> 1;
+        const int child = (int)((X & 1) | ((Y & 1) << 1) | ((Z & 1) << 2));
+        const unsigned long long bk = cell_pack(BX, BY, BZ);
+        unsigned int b = cell_hash(BX, BY, BZ) & bmask;
+        for (unsigned int probe = 0; probe <= bmask; ++probe) {
+            const unsigned long long old = atomicCAS(&bt[b].key, PCR_EMPTY_KEY, bk);
+            if (old == PCR_EMPTY_KEY || old == bk) break;
+            b = (b + 1) & bmask;
+        }
+        const unsigned int cnt = c.end - c.start;
+        if (cnt >= 0xffffu) atomicOr(&bt[b].flags, 1u);
+        bt[b].cnt[child] = (unsigned short)(cnt >= 0xffffu ? 0xffffu : cnt);
+        atomicMin(&bt[b].start, c.start);
+    }
+}
+
+unsigned int next_pow2_host(unsigned long long v) {
+    unsigned long long p = 1;
+    while (p < v) p <<= 1;
+    return (unsigned int)p;
+}
+
+struct dev_block {
+    pcr_ctx* ctx;
+    void* p = nullptr;
+    size_t bytes = 0;
+    explicit dev_block(pcr_ctx* c) : ctx(c) {}
+    int alloc(size_t b) { bytes = b; return pcr_dev_alloc(ctx, b, &p); }
+    ~dev_block() { if (p) pcr_dev_free(ctx, p, bytes); }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+// the per-pair path (what pcr_icp_batch did for every pair before the fused stages; still used for what they cannot take)
+int run_one_pair(pcr_ctx* ctx, const pcr_pair& P, const pcr_icp_params* params, pcr_icp_result* res) {
+    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    pcr_cloud *src = nullptr, *tgt = nullptr;
+    pcr_index* index = nullptr;
+    int rc = pcr_cloud_upload_f32(ctx, P.src, P.n_src, P.stride_src, &src);
+    if (rc == PCR_OK) rc = pcr_cloud_upload_f32(ctx, P.tgt, P.n_tgt, P.stride_tgt, &tgt);
+    if (rc == PCR_OK) rc = pcr_index_build(ctx, tgt, PCR_INDEX_GRID, 0.0, &index);
+    if (rc == PCR_OK) rc = pcr_icp(ctx, src, index, params, P.T0 ? P.T0 : eye, res);
+    if (index) pcr_index_free(ctx, index);
+    if (tgt) pcr_cloud_free(ctx, tgt);
+    if (src) pcr_cloud_free(ctx, src);
+    return rc;
+}
+
+struct batch_timing {
+    std::atomic<long long> ns[6];   // stage, set-up enqueue, ICP (incl. waiting for the set-up), read-back, fallbacks, sub-batches
+};
+
+// pinned host memory of a context, grown on demand (hipHostMalloc pins pages under a process-wide lock: kept across batches)
+int ensure_pinned(pcr_ctx* ctx, size_t bytes) {
+    if (ctx->h_stage_bytes >= bytes && ctx->h_stage) return PCR_OK;
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->h_stage) hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->h_stage_bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->last_error = "hipHostMalloc(batch staging)";
+        return PCR_E_NOMEM;
+    }
+    ctx->h_stage_bytes = want;
+    return PCR_OK;
+}
+
+// Registers pairs[ids[0..m)] in fused stages on ctx.  status[i] < 0 marks pairs that must take the per-pair path instead
+// (PCR_E_UNSUPPORTED as a private "not taken" mark) or that are invalid; results/status of the others are final.
+int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, const pcr_icp_params* params, pcr_icp_result* results,
+                int32_t* status, batch_timing* tm) {
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ns = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+    };
+    const auto t_begin = now();
+    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    hipSetDevice(ctx->device);
+    const int n_clouds = 2 * m;
+    // ---- slots: sources first (a source slot index is a query index of the pass kernels), then targets
+    std::vector<batch_cloud> cl(n_clouds);
+    std::vector<batch_target> tg(m);
+    std::vector<char> take(m, 1);
+    unsigned long long slots = 0;
+    for (int half = 0; half < 2; ++half)
+        for (int k = 0; k < m; ++k) {
+            const pcr_pair& P = pairs[ids[k]];
+            const int64_t n = half == 0 ? P.n_src : P.n_tgt, stride = half == 0 ? P.stride_src : P.stride_tgt;
+            const float* ptr = half == 0 ? P.src : P.tgt;
+            if (n <= 0 || stride < 3 || !ptr || n > (1 << 24)) take[k] = 0;   // empty / invalid / very large clouds: per-pair path decides
+        }
+    for (int half = 0; half < 2; ++half)
+        for (int k = 0; k < m; ++k) {
+            const pcr_pair& P = pairs[ids[k]];
+            const int64_t n = take[k] ? (half == 0 ? P.n_src : P.n_tgt) : 0;
+            batch_cloud& C = cl[half * m + k];
+            C.off = slots;
+            C.n = n;
+            slots += (unsigned long long)((n + SLOT - 1) / SLOT) * SLOT;
+        }
+    const unsigned long long src_slots = cl[m].off;
+    if (slots == 0 || slots >= (1ull << 31)) {
+        for (int k = 0; k < m; ++k) status[ids[k]] = PCR_E_UNSUPPORTED;
+        return PCR_OK;
+    }
+    // ---- pinned staging: packed xyz | clouds | targets | T0s ; read-back: states
+    const size_t xyz_bytes = (size_t)slots * 12;
+    const size_t off_cl = (xyz_bytes + 255) & ~(size_t)255, off_tg = off_cl + ((sizeof(batch_cloud) * n_clouds + 255) & ~(size_t)255);
+    const size_t off_T0 = off_tg + ((sizeof(batch_target) * m + 255) & ~(size_t)255), off_st = off_T0 + ((128 * (size_t)m + 255) & ~(size_t)255);
+    const size_t pinned_bytes = off_st + sizeof(pcr_icp_dev_state) * (size_t)m + 256;
+    int rc = ensure_pinned(ctx, pinned_bytes);
+    if (rc) return rc;
+    char* const hp = (char*)ctx->h_stage;
+    float* const h_xyz = (float*)hp;
+    std::vector<double> hi_all(3 * (size_t)n_clouds, 0.0);   // upper corners of the clouds' bounding boxes
+    for (int c = 0; c < n_clouds; ++c) {
+        const int k = c % m;
+        if (!take[k]) continue;
+        const pcr_pair& P = pairs[ids[k]];
+        const bool is_src = c < m;
+        const int64_t n = is_src ? P.n_src : P.n_tgt, stride = is_src ? P.stride_src : P.stride_tgt;
+        const float* ptr = is_src ? P.src : P.tgt;
+        batch_cloud& C = cl[c];
+        float* dst = h_xyz + 3 * C.off;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool finite = true;
+        for (int64_t i = 0; i < n; ++i) {   // (float -> double is exact: the box equals the one the per-pair path takes in binary64)
+            const float* p = ptr + i * stride;
+            const float x = p[0], y = p[1], z = p[2];
+            dst[3 * i + 0] = x; dst[3 * i + 1] = y; dst[3 * i + 2] = z;
+            finite = finite && std::isfinite(x) && std::isfinite(y) && std::isfinite(z);
+            lo[0] = x < lo[0] ? x : lo[0]; hi[0] = x > hi[0] ? x : hi[0];
+            lo[1] = y < lo[1] ? y : lo[1]; hi[1] = y > hi[1] ? y : hi[1];
+            lo[2] = z < lo[2] ? z : lo[2]; hi[2] = z > hi[2] ? z : hi[2];
+        }
+        if (!finite) { take[k] = 0; continue; }   // (the per-pair path reports it)
+        for (int a = 0; a < 3; ++a) { C.lo[a] = (double)lo[a]; hi_all[3 * (size_t)c + a] = (double)hi[a]; }
+    }
+    // grid parameters per pair: the functions the per-pair path uses, on the same boxes
+    int mbits = 3;
+    for (int k = 0; k < m; ++k) {
+        if (!take[k]) continue;
+        batch_cloud &S = cl[k], &T = cl[m + k];
+        const double *s_hi = &hi_all[3 * (size_t)k], *t_hi = &hi_all[3 * (size_t)(m + k)];
+        for (int a = 0; a < 3; ++a) tg[k].hi[a] = t_hi[a];
+        double cell = 0;
+        int levels = 1;
+        pcr_grid_plan(T.lo, t_hi, T.n, 0.0, &cell, &levels);
+        tg[k].cell = cell;
+        tg[k].levels = levels;
+        T.inv = 1.0 / cell;
+        // the source's curve (pcr_cloud_morton_sort): the target's cell, clamped to the source's own extent
+        const double emax_s = fmax(s_hi[0] - S.lo[0], fmax(s_hi[1] - S.lo[1], s_hi[2] - S.lo[2]));
+        double cell_s = cell;
+        if (cell_s < emax_s / 262144.0) cell_s = emax_s / 262144.0;
+        S.inv = 1.0 / cell_s;
+        double sc = 0, isc = 0;
+        if (!pcr_pass_fixed_scale(T.lo, t_hi, S.n, params->max_d2, &sc, &isc)) { take[k] = 0; continue; }   // absurd extents: per-pair path (binary64 slabs)
+        tg[k].scale = sc;
+        tg[k].inv_scale = isc;
+        const int bt = pcr_morton_end_bit(T.lo, t_hi, T.inv), bs = pcr_morton_end_bit(S.lo, s_hi, S.inv);
+        mbits = bt > mbits ? bt : mbits;
+        mbits = bs > mbits ? bs : mbits;
+    }
+    int cbits = 1;
+    while ((1 << cbits) < n_clouds) ++cbits;
+    bool any = false;
+    for (int k = 0; k < m; ++k) {
+        if (!take[k]) {
+            status[ids[k]] = PCR_E_UNSUPPORTED;
+            cl[k].n = 0;       // (its slots stay, empty: no tile of it does anything)
+            cl[m + k].n = 0;
+            tg[k].levels = 0;
+            tg[k].cell = 1.0; tg[k].scale = tg[k].inv_scale = 1.0;
+            for (int a = 0; a < 3; ++a) { tg[k].hi[a] = 0; cl[k].lo[a] = cl[m + k].lo[a] = 0; }
+            cl[k].inv = cl[m + k].inv = 1.0;
+        } else any = true;
+    }
+    if (!any || mbits + cbits > 63) {
+        for (int k = 0; k < m; ++k) status[ids[k]] = PCR_E_UNSUPPORTED;
+        return PCR_OK;
+    }
+    // table pools: rigorous upper bounds of what the plan kernel will hand out (cells of level l <= min(n, cells of the box))
+    unsigned long long cell_pool_slots = 0, block_pool_slots = 0;
+    for (int k = 0; k < m; ++k) {
+        if (!take[k]) continue;
+        const batch_cloud& T = cl[m + k];
+        for (int l = 0; l < tg[k].levels; ++l) {
+            double box = 1.0;
+            for (int a = 0; a < 3; ++a) {
+                const double k0 = floor((tg[k].hi[a] - T.lo[a]) * T.inv) + 2.0;
+                box *= floor(ldexp(k0, -2 * l)) + 1.0;
+            }
+            const unsigned long long bound = box < (double)T.n ? (unsigned long long)box : (unsigned long long)T.n;
+            unsigned int cap = next_pow2_host(bound * 4 + 4), bcap = next_pow2_host(bound * 2 + 4);
+            cell_pool_slots += cap < MIN_CAP ? MIN_CAP : cap;
+            block_pool_slots += bcap < MIN_CAP ? MIN_CAP : bcap;
+        }
+    }
+    memcpy(hp + off_cl, cl.data(), sizeof(batch_cloud) * n_clouds);
+    memcpy(hp + off_tg, tg.data(), sizeof(batch_target) * m);
+    double* const h_T0 = (double*)(hp + off_T0);
+    for (int k = 0; k < m; ++k) memcpy(h_T0 + 16 * (size_t)k, pairs[ids[k]].T0 ? pairs[ids[k]].T0 : eye, 128);
+    const auto t_staged = now();
+    // ---- device memory
+    const unsigned int n_tiles = (unsigned int)(src_slots / 32);
+    size_t items_bytes = 0, acc_bytes = 0, sync_word = 0;
+    unsigned int cap = 0;
+    pcr_grid_batch_scratch_bytes(n_tiles, m, &items_bytes, &acc_bytes, &sync_word, &cap);
+    const int n_e = m * PCR_MAX_LEVELS;
+    dev_block d_in(ctx), d_pts(ctx), d_keys(ctx), d_keys2(ctx), d_vals(ctx), d_vals2(ctx), d_tmp(ctx), d_cells(ctx), d_blocks(ctx), d_small(ctx), d_res(ctx),
+        d_prev(ctx), d_cost(ctx), d_items(ctx), d_acc(ctx), d_st(ctx), d_tp(ctx);
+    size_t temp_bytes = 0;
+    {
+        unsigned long long* kn = nullptr;
+        unsigned int* vn = nullptr;
+        if (rocprim::radix_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, (size_t)slots, 0, (unsigned int)(mbits + cbits), ctx->stream) != hipSuccess) return PCR_E_HIP;
+    }
+    // small things in one block: clouds | targets | T0s | counts | cell offsets | plan | pairs | running
+    const size_t s_cl = 0, s_tg = off_tg - off_cl, s_T0 = off_T0 - off_cl, s_in_end = off_st - off_cl;   // (same layout as the pinned block)
+    const size_t s_counts = s_in_end, s_coff = s_counts + ((4 * (size_t)n_e + 255) & ~(size_t)255), s_plan = s_coff + ((8 * ((size_t)n_e + 1) + 255) & ~(size_t)255);
+    const size_t s_pairs = s_plan + 256, s_run = s_pairs + ((sizeof(pcr_batch_pair) * m + 255) & ~(size_t)255), s_end = s_run + ((4 * (PCR_ICP_MAX_LOG + 1) + 255) & ~(size_t)255);
+    if ((rc = d_in.alloc(xyz_bytes)) || (rc = d_pts.alloc(sizeof(pcr_pt) * (size_t)slots)) || (rc = d_keys.alloc(8 * (size_t)slots)) ||
+        (rc = d_keys2.alloc(8 * (size_t)slots)) || (rc = d_vals.alloc(4 * (size_t)slots)) || (rc = d_vals2.alloc(4 * (size_t)slots)) ||
+        (rc = d_tmp.alloc(temp_bytes)) || (rc = d_cells.alloc(sizeof(pcr_cell_slot) * (size_t)cell_pool_slots)) ||
+        (rc = d_blocks.alloc(sizeof(pcr_block_slot) * (size_t)block_pool_slots)) || (rc = d_small.alloc(s_end)) || (rc = d_res.alloc(4 * (size_t)src_slots)) ||
+        (rc = d_prev.alloc(24 * (size_t)src_slots)) || (rc = d_cost.alloc(4 * (size_t)n_tiles)) || (rc = d_items.alloc(items_bytes)) ||
+        (rc = d_acc.alloc(acc_bytes)) || (rc = d_st.alloc(sizeof(pcr_icp_dev_state) * (size_t)m)) || (rc = d_tp.alloc(4 * (size_t)n_tiles)))
+        return rc;
+    char* const ds = d_small.as<char>();
+    const batch_cloud* d_cl = (const batch_cloud*)(ds + s_cl);
+    const batch_target* d_tg = (const batch_target*)(ds + s_tg);
+    const double* d_T0 = (const double*)(ds + s_T0);
+    unsigned int* d_counts = (unsigned int*)(ds + s_counts);
+    unsigned long long* d_coff = (unsigned long long*)(ds + s_coff);
+    batch_plan* d_plan = (batch_plan*)(ds + s_plan);
+    pcr_batch_pair* d_pairs = (pcr_batch_pair*)(ds + s_pairs);
+    unsigned int* d_running = (unsigned int*)(ds + s_run);
+    hipStream_t st = ctx->stream;
+    PCR_HIP(ctx, hipEventRecord(ctx->ev0, st));
+    // ---- uploads, keys, sort, records
+    PCR_HIP(ctx, hipMemcpyAsync(d_in.p, h_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
+    PCR_HIP(ctx, hipMemcpyAsync(ds, hp + off_cl, s_in_end, hipMemcpyHostToDevice, st));
+    PCR_HIP(ctx, hipMemsetAsync(ds + s_counts, 0, s_plan + 256 - s_counts, st));
+    const unsigned int blocks_all = (unsigned int)(slots / SLOT), blocks_src = (unsigned int)(src_slots / SLOT), blocks_tgt = blocks_all - blocks_src;
+    hipLaunchKernelGGL(batch_keys_kernel, dim3(blocks_all), dim3(SLOT), 0, st, d_in.as<float>(), d_cl, n_clouds, mbits, d_keys.as<unsigned long long>(),
+                       d_vals.as<unsigned int>());
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_tmp.p, temp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned int>(),
+                                           d_vals2.as<unsigned int>(), (size_t)slots, 0, (unsigned int)(mbits + cbits), st));
+    hipLaunchKernelGGL(batch_gather_kernel, dim3(blocks_all), dim3(SLOT), 0, st, d_in.as<float>(), d_vals2.as<unsigned int>(), d_cl, n_clouds, d_pts.as<pcr_pt>());
+    // ---- grids of all targets
+    if (blocks_tgt)
+        hipLaunchKernelGGL(batch_count_kernel, dim3(blocks_tgt), dim3(SLOT), 0, st, d_keys2.as<unsigned long long>(), d_cl, n_clouds, m, d_tg, src_slots, mbits, d_counts);
+    hipLaunchKernelGGL(batch_plan_kernel, dim3(1), dim3(256), 0, st, d_counts, d_cl, d_tg, m, d_pts.as<pcr_pt>(), d_cells.as<pcr_cell_slot>(), cell_pool_slots,
+                       d_blocks.as<pcr_block_slot>(), block_pool_slots, d_pairs, d_coff, d_plan);
+    hipLaunchKernelGGL(batch_init_tables_kernel, dim3(4 * ctx->cu_count), dim3(256), 0, st, d_cells.as<pcr_cell_slot>(), d_blocks.as<pcr_block_slot>(), d_plan, d_pairs, m,
+                       d_tp.as<unsigned int>(), n_tiles);
+    if (blocks_tgt)
+        hipLaunchKernelGGL(batch_insert_cells_kernel, dim3(blocks_tgt), dim3(SLOT), 0, st, d_keys2.as<unsigned long long>(), d_cl, n_clouds, m, d_pairs, src_slots, mbits,
+                           d_plan);
+    hipLaunchKernelGGL(batch_insert_blocks_kernel, dim3(8 * ctx->cu_count), dim3(256), 0, st, d_cells.as<pcr_cell_slot>(), d_coff, n_e, d_pairs, d_plan);
+    PCR_HIP(ctx, hipGetLastError());
+    // ---- ICP
+    pcr_batch_pass_args a{};
+    a.pairs = d_pairs;
+    a.n_pairs = m;
+    a.tile_pair = d_tp.as<unsigned int>();
+    a.n_tiles = n_tiles;
+    a.q = d_pts.as<pcr_pt>();
+    a.res_pos = d_res.as<unsigned int>();
+    a.prev_xyz = d_prev.p;
+    a.tile_cost = d_cost.as<unsigned int>();
+    a.items = d_items.as<unsigned long long>();
+    a.acc = d_acc.as<unsigned long long>();
+    a.sync = a.acc + sync_word;
+    a.cap = cap;
+    a.st = d_st.as<pcr_icp_dev_state>();
+    a.running = d_running;
+    a.la.max_iter = params->max_iter; a.la.min_iter = params->min_iter;
+    a.la.compat = params->mode == PCR_ICP_COMPAT_MAIN; a.la.r_metric = params->r_metric;
+    a.la.r_thres = params->r_thres; a.la.t_thres = params->t_thres;
+    a.max_d2 = params->max_d2;
+    if ((rc = pcr_grid_batch_init(ctx, &a, d_T0))) return rc;
+    PCR_HIP(ctx, hipEventRecord(ctx->ev2, st));
+    const auto t_enq = now();
+    int enq = 0;
+    int chunk = params->min_iter > 2 ? params->min_iter : 2;
+    unsigned int* const h_run = (unsigned int*)ctx->h_pinned;
+    while (enq < params->max_iter) {
+        if (chunk > params->max_iter - enq) chunk = params->max_iter - enq;
+        if (chunk > 64) chunk = 64;
+        for (int c = 0; c < chunk; ++c)
+            if ((rc = pcr_grid_batch_pass(ctx, &a, (unsigned int)(enq + c)))) return rc;
+        enq += chunk;
+        PCR_HIP(ctx, hipMemcpyAsync(h_run, d_running + (enq - 1), 4, hipMemcpyDeviceToHost, st));
+        PCR_HIP(ctx, hipStreamSynchronize(st));
+        if (*h_run == 0) break;
+        chunk *= 2;
+    }
+    PCR_HIP(ctx, hipEventRecord(ctx->ev1, st));
+    const auto t_icp = now();
+    pcr_icp_dev_state* const h_st = (pcr_icp_dev_state*)(hp + off_st);
+    batch_plan h_plan;
+    PCR_HIP(ctx, hipMemcpyAsync(h_st, a.st, sizeof(pcr_icp_dev_state) * (size_t)m, hipMemcpyDeviceToHost, st));
+    PCR_HIP(ctx, hipMemcpyAsync(&h_plan, d_plan, sizeof(h_plan), hipMemcpyDeviceToHost, st));
+    PCR_HIP(ctx, hipStreamSynchronize(st));
+    if (h_plan.overflow) { ctx->last_error = "batch: table pool bound exceeded"; return PCR_E_HIP; }
+    float icp_ms = 0;
+    hipEventElapsedTime(&icp_ms, ctx->ev2, ctx->ev1);
+    int n_take = 0;
+    for (int k = 0; k < m; ++k) n_take += take[k] ? 1 : 0;
+    for (int k = 0; k < m; ++k) {
+        if (!take[k]) continue;
+        const pcr_icp_dev_state& S = h_st[k];
+        pcr_icp_result* res = &results[ids[k]];
+        memset(res, 0, sizeof(*res));
+        double T_cur[16], T_total[16];
+        pcr::T_from_xform(S.x, T_cur);
+        memcpy(T_total, S.T_total, sizeof(T_total));
+        if (!a.la.compat && S.status == PCR_OK && !S.converged && S.it == params->max_iter && params->max_iter > 0)
+            pcr::T_mul4(T_cur, T_total, T_total);   // icp_template.py:195-198: a non-converged last iteration still updates homo_mat_total
+        res->iters = S.it;
+        res->status = S.status;
+        res->n_assoc = S.n_assoc;
+        res->cost = S.cost;
+        res->mean_d2 = S.mean_d2;
+        for (int i = 0; i < S.it && i < PCR_ICP_MAX_LOG; ++i) { res->r_diff[i] = S.r_diff[i]; res->t_diff[i] = S.t_diff[i]; }
+        res->nn_launches = S.passes;
+        res->device_ms = icp_ms / (double)n_take;   // the pair's share of the sub-batch's loop
+        memcpy(res->T_total, T_total, sizeof(T_total));
+        memcpy(res->T, a.la.compat ? T_cur : T_total, sizeof(T_cur));
+        status[ids[k]] = S.status;
+    }
+    if (tm) {
+        const auto t_end = now();
+        tm->ns[0] += ns(t_begin, t_staged);
+        tm->ns[1] += ns(t_staged, t_enq);
+        tm->ns[2] += ns(t_enq, t_icp);
+        tm->ns[3] += ns(t_icp, t_end);
+        tm->ns[5] += 1;
+    }
+    return PCR_OK;
+}
+
+}  // namespace
+
+extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_t n_pairs, const pcr_icp_params* params,
+                             pcr_icp_result* results, int32_t* status_out) {
+    if (!ctxs || n_ctx <= 0 || (n_pairs > 0 && (!pairs || !results)) || !params) return PCR_E_INVALID;
+    for (int c = 0; c < n_ctx; ++c)
+        if (!ctxs[c]) return PCR_E_INVALID;
+    if (params->max_iter > PCR_ICP_MAX_LOG) return PCR_E_TOO_MANY_ITERS;
+    if (n_pairs == 0) return PCR_OK;
+    // several worker contexts keep the device busy together: two-launch ICP passes for what takes the per-pair path
+    int was_shared[64];
+    for (int c = 0; c < n_ctx && c < 64; ++c) {
+        was_shared[c] = ctxs[c]->shared_device;
+        if (n_ctx > 1) ctxs[c]->shared_device = 1;
+    }
+    const char* per_pair_s = getenv("PCR_BATCH_PER_PAIR");   // read per call: the tests switch it
+    const bool gated = (params->max_d2 > 0) && std::isfinite(params->max_d2);
+    const bool fused = gated && !(per_pair_s && atoi(per_pair_s) != 0);
+    // sub-batches: big enough that a pair's share of the ~20 launches and 2 synchronisations is small, small enough that the
+    // workers' stages (host packing, copies, kernels) overlap each other
+    int64_t sub = 1;
+    if (fused) {
+        const char* s = getenv("PCR_BATCH_SUB");
+        sub = s ? atoll(s) : (n_pairs + 2 * n_ctx - 1) / (2 * n_ctx);
+        if (sub < 4) sub = n_pairs < 4 ? n_pairs : 4;
+        if (sub > 256) sub = 256;
+    }
+    const int64_t n_sub = (n_pairs + sub - 1) / sub;
+    std::vector<int32_t> status_own;
+    int32_t* status = status_out;
+    if (!status) { status_own.assign((size_t)n_pairs, 0); status = status_own.data(); }
+    std::atomic<int64_t> next(0);
+    std::atomic<int> hard_error(PCR_OK);
+    static const bool timing = getenv("PCR_BATCH_TIMING") != nullptr;
+    batch_timing tm;
+    for (auto& v : tm.ns) v = 0;
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto note_error = [&](int rc) {
+        if (rc < 0) {
+            int expected = PCR_OK;
+            hard_error.compare_exchange_strong(expected, rc);
+        }
+    };
+    auto worker = [&](pcr_ctx* ctx) {
+        hipSetDevice(ctx->device);
+        std::vector<int64_t> ids;
+        for (;;) {
+            const int64_t s = next.fetch_add(1);
+            if (s >= n_sub) break;
+            const int64_t lo = s * sub, hi = lo + sub < n_pairs ? lo + sub : n_pairs;
+            ids.clear();
+            for (int64_t i = lo; i < hi; ++i) { ids.push_back(i); status[i] = PCR_E_UNSUPPORTED; }
+            if (fused) {
+                const int rc = batch_fused(ctx, pairs, ids.data(), (int)ids.size(), params, results, status, timing ? &tm : nullptr);
+                if (rc) {   // the whole sub-batch failed on the way (out of memory, HIP error): its pairs take the per-pair path
+                    for (int64_t i = lo; i < hi; ++i) status[i] = PCR_E_UNSUPPORTED;
+                }
+            }
+            const auto tf0 = std::chrono::steady_clock::now();
+            for (int64_t i = lo; i < hi; ++i) {
+                if (status[i] != PCR_E_UNSUPPORTED) continue;
+                memset(&results[i], 0, sizeof(results[i]));
+                status[i] = run_one_pair(ctx, pairs[i], params, &results[i]);
+                note_error(status[i]);
+            }
+            if (timing) tm.ns[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
+        }
+    };
+    const int n_workers = (int)(n_sub < n_ctx ? n_sub : n_ctx);
+    if (n_workers <= 1) {
+        worker(ctxs[0]);
+    } else {
+        std::vector<std::thread> pool;
+        for (int c = 0; c < n_workers; ++c) pool.emplace_back(worker, ctxs[c]);
+        for (auto& t : pool) t.join();
+    }
+    for (int c = 0; c < n_ctx && c < 64; ++c) ctxs[c]->shared_device = was_shared[c];
+    if (timing)
+        fprintf(stderr, "pcr_icp_batch: %lld pairs, %lld sub-batches of <= %lld on %d contexts in %.2f ms; per sub-batch: pack %.0f us, set-up enqueue %.0f us, "
+                "ICP (incl. set-up kernels) %.0f us, read-back %.0f us; per-pair path %.0f us in total\n", (long long)n_pairs, (long long)tm.ns[5].load(), (long long)sub,
+                n_workers, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - wall0).count() / 1e3,
+                tm.ns[5] ? tm.ns[0] / 1e3 / tm.ns[5] : 0.0, tm.ns[5] ? tm.ns[1] / 1e3 / tm.ns[5] : 0.0, tm.ns[5] ? tm.ns[2] / 1e3 / tm.ns[5] : 0.0,
+                tm.ns[5] ? tm.ns[3] / 1e3 / tm.ns[5] : 0.0, tm.ns[4] / 1e3);
+    return hard_error.load();
+}

@@ -196,7 +196,7 @@ int pcr_bbox(pcr_ctx* ctx, const pcr_pt* pts, long long n, double lo[3], double 
 // Morton keys of a cloud whose coordinates span `ext` metres from its min corner: every cell coordinate is BIAS + k with
 // 0 <= k <= ext / cell, so only the low 3 * bits(k_max) key bits differ between points (the bias bit and the zeros below it
 // are the same for all): the radix sort only needs those (30 of 63 bits on a KITTI scan: half the passes).
-static int morton_end_bit(const double lo[3], const double hi[3], double inv) {
+int pcr_morton_end_bit(const double lo[3], const double hi[3], double inv) {
     double kmax = 0.0;
     for (int k = 0; k < 3; ++k) kmax = fmax(kmax, floor((hi[k] - lo[k]) * inv) + 2.0);   // +1 rounding slack, +1 for "count"
     int nb = 1;
@@ -213,13 +213,9 @@ int pcr_cloud_bbox(pcr_ctx* ctx, const pcr_cloud* c, double lo[3], double hi[3])
     return pcr_bbox(ctx, c->d, c->n, lo, hi);
 }
 
-// idx->lo/hi must already hold the target's bounding box (pcr_index_build computes it).
-int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* idx) {
-    const long long n = tgt->n;
-    const int block = 256;
-    const int grid_n = (int)((n + block - 1) / block);
-    int rc;
-    double lo[3] = {idx->lo[0], idx->lo[1], idx->lo[2]}, hi[3] = {idx->hi[0], idx->hi[1], idx->hi[2]};
+// Level-0 cell size and number of levels of the grid over a target with bounding box [lo, hi] and n points (cell_in > 0: the
+// caller's choice, still clamped).
+void pcr_grid_plan(const double lo[3], const double hi[3], long long n, double cell, double* cell_out, int* levels_out) {
     double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
     double emax = fmax(ext[0], fmax(ext[1], ext[2]));
     if (!(cell > 0)) {
@@ -240,6 +236,19 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
         double c = cell;
         while (c < emax * (1.0 + 1e-9) && levels < PCR_MAX_LEVELS) { c *= 4.0; ++levels; }
     }
+    *cell_out = cell;
+    *levels_out = levels;
+}
+
+// idx->lo/hi must already hold the target's bounding box (pcr_index_build computes it).
+int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* idx) {
+    const long long n = tgt->n;
+    const int block = 256;
+    const int grid_n = (int)((n + block - 1) / block);
+    int rc;
+    double lo[3] = {idx->lo[0], idx->lo[1], idx->lo[2]}, hi[3] = {idx->hi[0], idx->hi[1], idx->hi[2]};
+    int levels = 1;
+    pcr_grid_plan(lo, hi, n, cell, &cell, &levels);
     idx->cell = cell;
     // ---- keys, sort, gather
     unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
@@ -252,7 +261,7 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
     hipLaunchKernelGGL(morton_keys_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)tgt->d, n, lo[0], lo[1], lo[2],
                        inv, d_keys, d_vals);
     size_t temp_bytes = 0;
-    const int end_bit = morton_end_bit(lo, hi, inv);
+    const int end_bit = pcr_morton_end_bit(lo, hi, inv);
     PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
     void* d_temp = nullptr;
     if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;
@@ -353,7 +362,7 @@ int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell) {
     hipLaunchKernelGGL(morton_keys_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, n, lo[0], lo[1], lo[2],
                        1.0 / cell, d_keys, d_vals);
     size_t temp_bytes = 0;
-    const int end_bit = morton_end_bit(lo, hi, 1.0 / cell);
+    const int end_bit = pcr_morton_end_bit(lo, hi, 1.0 / cell);
     PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
     void* d_temp = nullptr;
     if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;

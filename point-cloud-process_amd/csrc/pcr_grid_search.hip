@@ -471,8 +471,10 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
         float bd = INFINITY;   // direct-form squared distance of this lane's best point so far
 #endif
         if (total > 0) {
+#if !PCR_WT_MFMA
             const f2 qx2 = {qxf, qxf}, qy2 = {qyf, qyf}, qz2 = {qzf, qzf};
             const int slice = lane / WT_Q;
+#endif
             unsigned int carry = 0;  // owner cell of the last position of the previous round
 #pragma unroll 1
             for (unsigned int base = 0; base < total; base += WT_PR) {
@@ -2002,6 +2004,24 @@ pass_init_kernel(unsigned long long* __restrict__ zero_p, unsigned int zero_n, u
     }
 }
 
+// Fraction bits of the fixed-point moment accumulators.  Every moment is bounded by M = N * max(R^2, gate, 1), R = half diagonal
+// of the target box + gate radius: totals stay below 2^61, one correspondence's moments below 2^51 (to_fixed).
+bool pcr_pass_fixed_scale(const double lo[3], const double hi[3], long long nq, double max_d2, double* scale, double* inv_scale) {
+    double r2 = 0.0;
+    for (int k = 0; k < 3; ++k) r2 += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]);
+    const double R = sqrt(r2) + sqrt(max_d2);
+    const double M = (double)nq * fmax(fmax(R * R, max_d2), 1.0);
+    int ex = 0;
+    frexp(M, &ex);              // M < 2^ex
+    int exq = 0;
+    frexp(M / (double)nq, &exq);   // one correspondence's moments < 2^exq
+    const int F = (61 - ex < 51 - exq) ? 61 - ex : 51 - exq;
+    if (!(M > 0) || !std::isfinite(M) || F < 20) return false;
+    *scale = ldexp(1.0, F);
+    *inv_scale = ldexp(1.0, -F);
+    return true;
+}
+
 // ICP loops of this process in flight per device (any context)
 static std::atomic<int> g_loops_in_flight[64];   // per device ordinal (zero-initialised)
 struct loop_guard {
@@ -2032,16 +2052,8 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     pass_args pa{};
     bool fused = gated && nq <= PASS_MAX_NQ && getenv("PCR_ICP_NO_FUSED") == nullptr;
     if (fused) {
-        double r2 = 0.0;
-        for (int k = 0; k < 3; ++k) r2 += 0.25 * (idx->hi[k] - idx->lo[k]) * (idx->hi[k] - idx->lo[k]);
-        const double R = sqrt(r2) + sqrt(params->max_d2);
-        const double M = (double)nq * fmax(fmax(R * R, params->max_d2), 1.0);
-        int ex = 0;
-        frexp(M, &ex);              // M < 2^ex
-        int exq = 0;
-        frexp(M / (double)nq, &exq);   // one correspondence's moments < 2^exq
-        const int F = (61 - ex < 51 - exq) ? 61 - ex : 51 - exq;   // totals below 2^61, single values below 2^51 (to_fixed)
-        if (!(M > 0) || !std::isfinite(M) || F < 20) fused = false;   // absurd extents: keep the binary64 slabs
+        double sc_f = 0, sc_i = 0;
+        if (!pcr_pass_fixed_scale(idx->lo, idx->hi, nq, params->max_d2, &sc_f, &sc_i)) fused = false;   // absurd extents: keep the binary64 slabs
         else {
             pa.cap = pass_item_cap(nq);
             if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS), (void**)&sc.acc)) ||
@@ -2055,8 +2067,8 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             pa.acc = sc.acc;
             pa.sync = sc.acc + ACC_SETS * PCR_NMOM;
             pa.prev_xyz = (wt_xyz*)sc.prev_xyz;
-            pa.scale = ldexp(1.0, F);
-            pa.inv_scale = ldexp(1.0, -F);
+            pa.scale = sc_f;
+            pa.inv_scale = sc_i;
         }
     }
     pcr_icp_dev_state* d_st = nullptr;
@@ -2173,5 +2185,223 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     memcpy(res->T_total, h_st->T_total, sizeof(double) * 16);
     if (la.compat) memcpy(res->T, T_cur, sizeof(T_cur));
     else memcpy(res->T, h_st->T_total, sizeof(double) * 16);
+    return PCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused batch of registrations (Registration/main.py:190-216: the loop over scan pairs): the same tile / queue / finish code as
+// above, one launch per STAGE for every pair of the batch.  A wave finds its pair through tile_pair[], reads the pair's grid
+// view, source slot and loop state through the (wave-uniform) descriptor pointer, and adds into the pair's own accumulator
+// sets; queue items carry the GLOBAL source slot, from which the serving wave finds the pair again.  Always the two-launch
+// ("throughput") variant of the pass -- many pairs share the device by construction -- followed by one wave per pair for the
+// Procrustes step: what a wave adds to the accumulators never depends on who serves what, so every pair's result is
+// bit-identical to pcr_icp on that pair alone.
+__device__ static inline const pcr_batch_pair* batch_pair_ptr(const pcr_batch_pass_args& B, unsigned int p) {
+    return as_global(B.pairs) + p;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
+batch_pass_kernel(pcr_batch_pass_args B, int xcd_remap, unsigned int pcap, unsigned int pass_id, int use_prev) {
+    __shared__ pass_lds s_lds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int tile_g = (unsigned int)__builtin_amdgcn_readfirstlane((int)(wtile_block(xcd_remap) * 4 + wave));
+    const unsigned int p = (unsigned int)__builtin_amdgcn_readfirstlane((int)as_global(B.tile_pair)[tile_g]);
+    if (p >= (unsigned int)B.n_pairs) return;   // (slot of a pair that was rejected on the host)
+    const pcr_batch_pair* const bp = batch_pair_ptr(B, p);
+    const unsigned long long q_off = bp->q_off;
+    const long long nq = bp->nq;
+    const unsigned int tile = tile_g - (unsigned int)(q_off / WT_Q);
+    pcr_pt* const q = B.q + q_off;
+    unsigned int* const res_pos = B.res_pos + q_off;
+    wt_xyz* const prev_xyz = (wt_xyz*)B.prev_xyz + q_off;
+    const pcr_icp_dev_state* const st = as_global(B.st) + p;
+    wt_pre P;
+    wtile_preload(tile, lane, q, nq, res_pos, use_prev ? prev_xyz : nullptr, P);
+    const unsigned int last_cost = use_prev ? B.tile_cost[tile_g] : 0u;
+    const pcr_xform x = st->x;
+    if (st->stop) return;
+    {
+        const unsigned int lc = (unsigned int)__builtin_amdgcn_readfirstlane((int)last_cost);
+        const unsigned int c = lc & 0xffffu, had_open = lc >> 16;
+        if (c > 3 * WT_PR) __builtin_amdgcn_s_setprio(3);
+        else if (c > 2 * WT_PR) __builtin_amdgcn_s_setprio(2);
+        else if (c > WT_PR || had_open) __builtin_amdgcn_s_setprio(1);
+    }
+    pass_lds* L = &s_lds[wave];
+    const unsigned int n_waves = gridDim.x * 4;
+    const unsigned int g = tile_g % PASS_GROUPS;
+    const unsigned int n_groups = n_waves < (unsigned int)PASS_GROUPS ? n_waves : (unsigned int)PASS_GROUPS;
+    const double max_d2 = B.max_d2;
+    wt_state S;
+    wtile_search(bp->gv, &L->t, tile, lane, P, q, nq, x, 1, 1, max_d2, 1, pcap, res_pos, nullptr, nullptr, use_prev ? prev_xyz : nullptr, S);
+    wave_sync();
+    __builtin_amdgcn_s_setprio(0);
+    {
+        const unsigned int n_open = (unsigned int)__popcll(__ballot(S.open && lane < WT_Q));
+        if (lane == 0) B.tile_cost[tile_g] = (S.staged < 0xffffu ? S.staged : 0xffffu) | (n_open << 16);
+    }
+    const bool proven = lane < WT_Q && S.won != POS_NONE;
+    pcr_pt nb;
+    nb.x = nb.y = nb.z = 0.0; nb.id = 0;
+    const bool nb_known = proven && S.won == P.seed_pos;
+    if (proven && !nb_known) nb = as_global(bp->gv.pts)[S.won];
+    // ---- open queries: the k-th one reserves a slot in group (g + k) mod groups (one vector atomic), then stores its item
+    const bool unres = S.open && lane < WT_Q;
+    const unsigned long long um = __ballot(unres);
+    if (um) {
+        const unsigned int rank = (unsigned int)__popcll(um & ((1ull << lane) - 1ull));
+        const unsigned int tg = (g + rank) % n_groups;
+        unsigned long long slot_w = 0;
+        if (unres) {
+            slot_w = __hip_atomic_fetch_add(B.sync + (size_t)PASS_SYNC_STRIDE * tg, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* it = B.items + ((size_t)tg * B.cap + (size_t)(slot_w & Q_MASK)) * 4;
+            const bool cand = !S.clamped && S.cand_pos != POS_NONE;
+            it[0] = S.ax == S.ax ? (unsigned long long)__double_as_longlong(S.ax) : 0x7ff8000000000000ull;
+            it[1] = S.ay == S.ay ? (unsigned long long)__double_as_longlong(S.ay) : 0x7ff8000000000000ull;
+            it[2] = S.az == S.az ? (unsigned long long)__double_as_longlong(S.az) : 0x7ff8000000000000ull;
+            it[3] = (unsigned long long)(unsigned int)(q_off + (unsigned long long)S.qi) | ((unsigned long long)__float_as_uint(cand ? S.bound2 : INFINITY) << 32);
+        }
+    }
+    // ---- moments of the proven queries: rounded to fixed point one by one, summed as integers, 19 atomics per wave
+    {
+        double m[PCR_NMOM];
+#pragma unroll
+        for (int k = 0; k < PCR_NMOM; ++k) m[k] = 0.0;
+        if (proven) {
+            if (nb_known) { nb.x = P.seed_b.x; nb.y = P.seed_b.y; nb.z = P.seed_b.z; }
+            else prev_xyz[S.qi] = wt_xyz{nb.x, nb.y, nb.z};
+            moments_add(m, bp->gv.origin, S.ax, S.ay, S.az, nb, max_d2, 1);
+        }
+        const double scale = bp->scale;
+        if (lane < WT_Q) {
+#pragma unroll
+            for (int k = 0; k < PCR_NMOM - 1; ++k) L->xll[lane * (PCR_NMOM - 1) + k] = to_fixed(m[k], scale);
+        }
+        wave_sync();
+        long long tot = 0;
+        if (lane < PCR_NMOM - 1) {
+#pragma unroll 8
+            for (int j = 0; j < WT_Q; ++j) tot += L->xll[j * (PCR_NMOM - 1) + lane];
+        }
+        acc_fixed_add_ll(B.acc + (size_t)p * ACC_SETS * PCR_NMOM, tile, lane, tot);
+    }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
+batch_drain_kernel(pcr_batch_pass_args B) {
+    __shared__ pass_lds s_lds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    pass_lds* L = &s_lds[wave];
+    const unsigned int l_cnt = lane < PASS_GROUPS ? (unsigned int)(B.sync[(size_t)PASS_SYNC_STRIDE * lane] & Q_MASK) : 0u;
+    unsigned int total = 0;
+    const unsigned int l_exc = wave_excl_scan_u32(l_cnt, lane, &total);
+    const unsigned int n_waves = gridDim.x * 4;
+    for (unsigned int w_i = blockIdx.x * 4 + wave; w_i < total; w_i += n_waves) {
+        const int grp = (int)__ffsll((long long)__ballot(lane < PASS_GROUPS && l_exc <= w_i && w_i < l_exc + l_cnt)) - 1;
+        const unsigned int idx = w_i - (unsigned int)__builtin_amdgcn_readlane((int)l_exc, grp);
+        unsigned long long* it = B.items + ((size_t)grp * B.cap + idx) * 4;
+        unsigned long long w = ITEM_NONE;
+        if (lane < 4) {
+            w = it[lane];
+            it[lane] = ITEM_NONE;   // the slot is clean for the next pass
+        }
+        const unsigned int slot = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w, 3);   // global source slot of the query
+        const unsigned int p = (unsigned int)__builtin_amdgcn_readfirstlane((int)as_global(B.tile_pair)[slot / WT_Q]);
+        const pcr_batch_pair* const bp = batch_pair_ptr(B, p);
+        pass_args A{};
+        A.acc = B.acc + (size_t)p * ACC_SETS * PCR_NMOM;
+        A.prev_xyz = (wt_xyz*)B.prev_xyz;
+        A.scale = bp->scale;
+        pass_serve_item(bp->gv, L, lane, w, B.max_d2, A, B.res_pos, nullptr, w_i, 0ull);
+    }
+}
+
+// one wave per pair: totals of the pair's accumulators -> Procrustes step -> convergence test -> the pair's loop state
+__global__ void __launch_bounds__(256)
+batch_finish_kernel(pcr_batch_pass_args B, unsigned int pass_id) {
+    __shared__ pass_lds s_lds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && wave == 0 && lane < PASS_GROUPS) B.sync[(size_t)PASS_SYNC_STRIDE * lane] = 0ull;   // queue words: clean for the next pass
+    const unsigned int p = (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    if (p >= (unsigned int)B.n_pairs) return;
+    pcr_icp_dev_state* const st = B.st + p;
+    if (as_global(st)->stop) return;   // stopped before this pass: its tiles did nothing
+    const pcr_batch_pair* const bp = batch_pair_ptr(B, p);
+    if (bp->nq <= 0) return;
+    pass_lds* L = &s_lds[wave];
+    pass_args A{};
+    A.acc = B.acc + (size_t)p * ACC_SETS * PCR_NMOM;
+    A.st = st;
+    A.la = B.la;
+    A.inv_scale = bp->inv_scale;
+    unsigned long long* const root = B.sync + (size_t)PASS_SYNC_STRIDE * PASS_GROUPS;   // (root + 16: the error word, never set here)
+    pass_finish(bp->gv, L, lane, A, root, nullptr);
+    wave_sync();
+    if (lane == 0 && !reinterpret_cast<const pcr_icp_dev_state*>(L->xch + 32)->stop) atomicAdd(B.running + pass_id, 1u);
+}
+
+// everything a batch wants initialised, in one launch: item slots all-ones, accumulators / queue words / running counts zero,
+// every pair's loop state built from its T0 (what pcr_grid_icp_loop writes for one pair)
+__global__ void __launch_bounds__(256)
+batch_init_kernel(unsigned long long* __restrict__ zero_p, unsigned long long zero_n, unsigned long long* __restrict__ ones_p, unsigned long long ones_n,
+                  unsigned int* __restrict__ running, pcr_icp_dev_state* __restrict__ st, int n_pairs, const double* __restrict__ T0) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long i = t0; i < ones_n; i += stride) ones_p[i] = ~0ull;
+    for (unsigned long long i = t0; i < zero_n; i += stride) zero_p[i] = 0ull;
+    for (unsigned long long i = t0; i < PCR_ICP_MAX_LOG + 1; i += stride) running[i] = 0u;
+    for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+        pcr_icp_dev_state* s = st + p;
+        unsigned long long* w = reinterpret_cast<unsigned long long*>(s);
+        for (unsigned int i = threadIdx.x; i < sizeof(pcr_icp_dev_state) / 8; i += blockDim.x) w[i] = 0ull;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double* T = T0 + 16 * (size_t)p;
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) {
+                    s->x.r[3 * i + j] = T[4 * i + j];
+                    s->R_last[3 * i + j] = T[4 * i + j];
+                }
+                s->x.t[i] = T[4 * i + 3];
+                s->t_last[i] = T[4 * i + 3];
+            }
+            for (int i = 0; i < 16; ++i) s->T_total[i] = (i % 5 == 0) ? 1.0 : 0.0;
+            for (int i = 0; i < 9; ++i) s->V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            s->first = 1;
+        }
+        __syncthreads();
+    }
+}
+
+void pcr_grid_batch_scratch_bytes(unsigned int n_tiles, int n_pairs, size_t* items_bytes, size_t* acc_sync_bytes, size_t* sync_word, unsigned int* cap) {
+    *sync_word = (size_t)n_pairs * ACC_SETS * PCR_NMOM;   // the queue words follow the accumulators
+    const unsigned int c = pass_item_cap((long long)n_tiles * WT_Q);
+    *cap = c;
+    *items_bytes = 32 * (size_t)PASS_GROUPS * c;
+    *acc_sync_bytes = sizeof(unsigned long long) * ((size_t)n_pairs * ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS);
+}
+
+int pcr_grid_batch_init(pcr_ctx* ctx, const pcr_batch_pass_args* a, const double* d_T0) {
+    // a->acc and a->sync are one allocation: [n_pairs][ACC_SETS][PCR_NMOM] accumulators, then the queue words
+    const unsigned long long zero_n = (unsigned long long)a->n_pairs * ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS;
+    const unsigned long long ones_n = 4ull * PASS_GROUPS * a->cap;
+    long long ib = (long long)((ones_n + 256 * 8 - 1) / (256 * 8));
+    if (ib < a->n_pairs) ib = a->n_pairs;
+    hipLaunchKernelGGL(batch_init_kernel, dim3((unsigned int)(ib < 1 ? 1 : (ib > 2048 ? 2048 : ib))), dim3(256), 0, ctx->stream, a->acc, zero_n, a->items, ones_n,
+                       a->running, a->st, a->n_pairs, d_T0);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_grid_batch_pass(pcr_ctx* ctx, const pcr_batch_pass_args* a, unsigned int pass_id) {
+    if (a->n_tiles == 0) return PCR_OK;
+    static const int rounds_env = getenv("PCR_BATCH_WT_ROUNDS") ? atoi(getenv("PCR_BATCH_WT_ROUNDS")) : 0;
+    const unsigned int pcap = (unsigned int)WT_PR * (rounds_env > 0 ? rounds_env : WT_ROUNDS_LARGE);
+    static const bool no_prev = getenv("PCR_NO_PREV") != nullptr;
+    hipLaunchKernelGGL(batch_pass_kernel, dim3(a->n_tiles / 4), dim3(256), 0, ctx->stream, *a, wtile_xcd_remap(), pcap, pass_id, (pass_id > 0 && !no_prev) ? 1 : 0);
+    const long long want = (long long)a->n_tiles * WT_Q / 4;
+    const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
+    hipLaunchKernelGGL(batch_drain_kernel, dim3(g3), dim3(256), 0, ctx->stream, *a);
+    hipLaunchKernelGGL(batch_finish_kernel, dim3((a->n_pairs + 3) / 4), dim3(256), 0, ctx->stream, *a, pass_id);
+    PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }

@@ -202,70 +202,6 @@ int pcr_icp(pcr_ctx* ctx, pcr_cloud* source, const pcr_index* index, const pcr_i
     return res->status;
 }
 
-int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_t n_pairs, const pcr_icp_params* params,
-                  pcr_icp_result* results, int32_t* status_out) {
-    if (!ctxs || n_ctx <= 0 || (n_pairs > 0 && (!pairs || !results)) || !params) return PCR_E_INVALID;
-    for (int c = 0; c < n_ctx; ++c)
-        if (!ctxs[c]) return PCR_E_INVALID;
-    // several worker contexts keep the device busy together: two-launch ICP passes (pcr_ctx_set_shared); restored on return
-    int was_shared[64];
-    for (int c = 0; c < n_ctx && c < 64; ++c) {
-        was_shared[c] = ctxs[c]->shared_device;
-        if (n_ctx > 1) ctxs[c]->shared_device = 1;
-    }
-    std::atomic<int64_t> next(0);
-    std::atomic<int> hard_error(PCR_OK);
-    static const bool timing = getenv("PCR_BATCH_TIMING") != nullptr;   // diagnostics: mean microseconds per phase and pair
-    std::atomic<long long> t_ns[4] = {{0}, {0}, {0}, {0}};
-    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    const auto wall0 = std::chrono::steady_clock::now();
-    auto worker = [&](pcr_ctx* ctx) {
-        hipSetDevice(ctx->device);
-        for (;;) {
-            const int64_t i = next.fetch_add(1);
-            if (i >= n_pairs || hard_error.load() != PCR_OK) break;
-            const pcr_pair& P = pairs[i];
-            pcr_cloud *src = nullptr, *tgt = nullptr;
-            pcr_index* index = nullptr;
-            auto now = [] { return std::chrono::steady_clock::now(); };
-            auto t0 = now();
-            int rc = pcr_cloud_upload_f32(ctx, P.src, P.n_src, P.stride_src, &src);
-            if (rc == PCR_OK) rc = pcr_cloud_upload_f32(ctx, P.tgt, P.n_tgt, P.stride_tgt, &tgt);
-            auto t1 = now();
-            if (rc == PCR_OK) rc = pcr_index_build(ctx, tgt, PCR_INDEX_GRID, 0.0, &index);
-            auto t2 = now();
-            if (rc == PCR_OK) rc = pcr_icp(ctx, src, index, params, P.T0 ? P.T0 : eye, &results[i]);
-            auto t3 = now();
-            if (timing) {
-                t_ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
-                t_ns[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
-                t_ns[2] += std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count();
-            }
-            if (status_out) status_out[i] = rc;
-            if (index) pcr_index_free(ctx, index);
-            if (tgt) pcr_cloud_free(ctx, tgt);
-            if (src) pcr_cloud_free(ctx, src);
-            if (rc < 0) {
-                int expected = PCR_OK;
-                hard_error.compare_exchange_strong(expected, rc);
-            }
-        }
-    };
-    if (n_ctx == 1) {
-        worker(ctxs[0]);
-    } else {
-        std::vector<std::thread> pool;
-        for (int c = 0; c < n_ctx; ++c) pool.emplace_back(worker, ctxs[c]);
-        for (auto& t : pool) t.join();
-    }
-    for (int c = 0; c < n_ctx && c < 64; ++c) ctxs[c]->shared_device = was_shared[c];
-    if (timing && n_pairs > 0)
-        fprintf(stderr, "pcr_icp_batch: %lld pairs on %d contexts in %.2f ms; per pair: uploads %.0f us, index build %.0f us, icp %.0f us\n", (long long)n_pairs,
-                n_ctx, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - wall0).count() / 1e3,
-                t_ns[0] / 1e3 / n_pairs, t_ns[1] / 1e3 / n_pairs, t_ns[2] / 1e3 / n_pairs);
-    return hard_error.load();
-}
-
 int pcr_procrustes(const double* A, const double* B, int64_t k, double R_out[9], double t_out[3], double* cost_out) {
     if (!A || !B || !R_out || !t_out) return PCR_E_INVALID;
     if (k <= 0) return PCR_E_EMPTY;

@@ -202,3 +202,44 @@ struct pcr_icp_loop_args {
 PCR_HIDDEN int pcr_d2h_staged(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
 PCR_HIDDEN int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_icp_params* params, const double T0[16],
                                  pcr_icp_result* res);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused batch of registrations (pcr_batch.hip, Registration/main.py:190-216): one launch per STAGE for all pairs.
+// The sources of all pairs live in ONE record array (pair p at [q_off, q_off + nq), Morton ordered, slots padded to
+// whole blocks of 8 wave tiles), every pair has its own target grid, accumulator sets and loop state.
+struct pcr_batch_pair {
+    pcr_grid_view gv;            // the target's grid (pointers into the batch's pools)
+    unsigned long long q_off;    // first source record = 32 x first wave tile
+    long long nq;                // source points (<= slot size)
+    double scale, inv_scale;     // 2^F, 2^-F of the pair's fixed-point moment accumulators
+};
+struct pcr_batch_pass_args {
+    const pcr_batch_pair* pairs;       // device [n_pairs]
+    int n_pairs;
+    const unsigned int* tile_pair;     // device [n_tiles]: pair of every wave tile
+    unsigned int n_tiles;              // multiple of 4
+    pcr_pt* q;                         // all source records
+    unsigned int* res_pos;             // [32 * n_tiles]
+    void* prev_xyz;                    // [32 * n_tiles] x 24 B
+    unsigned int* tile_cost;           // [n_tiles]
+    unsigned long long* items;         // work queue [groups][cap][4], all-ones between passes
+    unsigned long long* sync;          // queue words, zero between passes
+    unsigned int cap;
+    unsigned long long* acc;           // [n_pairs][sets][PCR_NMOM] fixed-point accumulators, zero between passes
+    pcr_icp_dev_state* st;             // [n_pairs]
+    unsigned int* running;             // [PCR_ICP_MAX_LOG + 1]: pairs still iterating after pass i
+    pcr_icp_loop_args la;
+    double max_d2;
+};
+// bytes of the queue / accumulator scratch a batch of that shape needs (items, sync + acc)
+PCR_HIDDEN void pcr_grid_batch_scratch_bytes(unsigned int n_tiles, int n_pairs, size_t* items_bytes, size_t* acc_sync_bytes, size_t* sync_word, unsigned int* cap);
+// states from T0 (device array [n_pairs][16]), queue and accumulators initialised: one launch
+PCR_HIDDEN int pcr_grid_batch_init(pcr_ctx* ctx, const pcr_batch_pass_args* a, const double* d_T0);
+// one ICP pass over every pair that has not stopped: tiles (publish) -> queue (drain) -> per-pair Procrustes step
+PCR_HIDDEN int pcr_grid_batch_pass(pcr_ctx* ctx, const pcr_batch_pass_args* a, unsigned int pass_id);
+// exactly the grid parameters pcr_grid_build derives from the target's box (shared so that a batch builds the same grid)
+PCR_HIDDEN void pcr_grid_plan(const double lo[3], const double hi[3], long long n, double cell_in, double* cell_out, int* levels_out);
+PCR_HIDDEN int pcr_morton_end_bit(const double lo[3], const double hi[3], double inv);
+// fixed-point scale of the one-launch pass for a target box / source size / gate; false: cannot use the fused pass
+PCR_HIDDEN bool pcr_pass_fixed_scale(const double lo[3], const double hi[3], long long nq, double max_d2, double* scale, double* inv_scale);
+
