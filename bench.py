@@ -4,8 +4,9 @@
 A "step" is one point-to-point ICP iteration on a 120 000 x 120 000-point
 KITTI-shaped synthetic scan pair (BASELINE.json configs[1]): in-place source
 transform + exact 1-NN of every source point + d2 < 5 gate + Procrustes moment
-accumulation on the GPU, 160-byte read-back, 3x3 SVD on the host.  Inputs and
-the target index are resident in HBM before the timed region.
+accumulation + 3x3 Procrustes step + convergence test, all on the GPU in ONE
+launch per iteration (the loop state lives on the device; the host only enqueues
+passes).  Inputs and the target index are resident in HBM before the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--nn grid|brute]
 
@@ -15,10 +16,13 @@ GPU call is made here) and relays their output; under torch.distributed.run
 (WORLD_SIZE set) it is one of the ranks.  One process per GPU: every rank
 registers its own independent 120k pair (the path shards across pairs, never
 inside one), results are gathered with one all_gather over
-RCCL, the timing is the max over ranks.  A second block, "batch256", runs
-BASELINE configs[3] (256 registration_dataset-shaped pairs of 20 000 6-float
-records) through register_batch: block-sharded over the ranks, one RCCL
-all_gather of the result records.  Rank 0 prints ONE JSON line.
+RCCL, the timing is the max over ranks.  Further blocks of the same JSON line:
+"batch256" = BASELINE configs[3] (256 registration_dataset-shaped pairs of
+20 000 6-float records) through register_batch -> pcr_icp_batch (fused batch
+stages), block-sharded over the ranks, one RCCL all_gather of the result
+records; "config3" = configs[2] (0.2 m voxel filter of both 120k clouds -> ICP);
+"config5" = configs[4] (1 M-point ISS + coarse-to-fine ICP), N = 1 only.
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -209,9 +213,12 @@ def filter_pairs_per_pass(pkg, dev_id, src, tgt, cell):
 
 def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
     """BASELINE configs[3]: 256 pairs x 20 000-point 6-float records (Registration/main.py:190-216 is the loop being
-    sharded) through register_batch -- upload, index build and ICP of every pair inside the timed region, one all_gather
-    of the result records.  Two passes: the reference's own stopping rule (compat, thresholds 0.5: 1-2 iterations) and a
-    tight one (composed transform, thresholds 1e-3, at most 30 iterations)."""
+    sharded) through register_batch with its default worker: the rank's share goes through ONE C call, pcr_icp_batch
+    (fused batch stages: host packing, upload, index build and ICP of every pair inside the timed region), then one
+    all_gather of the result records.  Two passes: the reference's own stopping rule (compat, thresholds 0.5: 1-2
+    iterations) and a tight one (composed transform, thresholds 1e-3, at most 30 iterations).  At N = 1 also the
+    per-pair path (PCR_BATCH_PER_PAIR=1: upload -> index build -> pcr_icp per pair on the same contexts) and a profiled,
+    untimed run for the dominant kernel's roofline."""
     batch = importlib.import_module("point-cloud-process_amd.batch")
     lo, hi = batch.shard_range(BATCH_PAIRS, rank, world)
     mine = pkg.synthetic.registration_batch_6f(BATCH_PAIRS, BATCH_POINTS, seed=1000, indices=range(lo, hi))
@@ -220,38 +227,162 @@ def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
     for i, (s6, t6, Tt) in zip(range(lo, hi), mine):
         pairs[i] = (s6, t6, None)
         truth[i] = Tt
+    for i in range(BATCH_PAIRS):   # other ranks' pairs are never touched: placeholders keep the list length
+        if pairs[i] is None:
+            pairs[i] = (None, None, None)
     out = {"pairs": BATCH_PAIRS, "points_per_cloud": BATCH_POINTS, "record": "6 x f32 (x,y,z,nx,ny,nz)", "streams_per_gpu": streams,
-           "pairs_per_gpu": hi - lo}
-    for tag, kw in (("compat", dict(mode="compat")), ("tight", dict(mode="total", max_iter=30, r_thres=1e-3, t_thres=1e-3))):
-        fn = batch.gpu_register_fn(device=dev_id, streams=streams, **kw)
-        for k in range(min(streams, hi - lo)):  # warm every context (arena, pinned buffers, code objects), untimed
-            fn(k, pairs[lo + k][0], pairs[lo + k][1], None)
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        res = batch.register_batch(pairs, register_fn=fn)
-        if dist is not None:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            tm = torch.tensor([el], dtype=torch.float64, device=tdev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            el = float(tm.item())
+           "pairs_per_gpu": hi - lo, "entry_point": "pcr_icp_batch (fused batch stages) via register_batch(pairs, device=..., streams=...)"}
+    modes = (("compat", dict(mode="compat")), ("tight", dict(mode="total", max_iter=30, r_thres=1e-3, t_thres=1e-3)))
+
+    def timed(kw, reps):
+        best, res = None, None
+        for _ in range(reps):
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            res = batch.register_batch(pairs, device=dev_id, streams=streams, **kw)
+            if dist is not None:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                tm = torch.tensor([el], dtype=torch.float64, device=tdev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                el = float(tm.item())
+            best = el if best is None else min(best, el)
+        return best, res
+
+    for tag, kw in modes:
+        batch.native_register_share(pairs[lo:hi], device=dev_id, streams=streams, **kw)   # warm the pooled contexts (arenas, pinned buffers, code objects), untimed
+        el, res = timed(kw, 3)
         iters = np.array([r["iters"] for r in res])
         errs = [float(np.linalg.norm(res[i]["T"] - truth[i])) for i in truth] if tag == "tight" else []
         out[tag] = {"seconds": el, "pairs_per_s": BATCH_PAIRS / el, "pairs_per_s_per_gpu": BATCH_PAIRS / el / world,
-                    # both clouds of every pair as 16-B records over the wall time, against N x 8 TB/s: this block is
-                    # bound by per-pair host work (uploads, index build, synchronisations), not by HBM
+                    "timing": "best of 3 runs of the whole batch (host packing + H2D + index builds + ICP + gather)",
+                    # both clouds of every pair as 16-B records over the wall time, against N x 8 TB/s
                     "hbm_frac_algorithmic": BATCH_PAIRS * 2 * BATCH_POINTS * 16 / el / (HBM_PEAK_GBS * 1e9 * world),
+                    "pcie_bytes": (hi - lo) * 2 * BATCH_POINTS * 12,
                     "correspondences_per_s": float(iters.sum()) * BATCH_POINTS / el, "mean_iters": float(iters.mean()),
                     "results_gathered": len(res)}
         if errs:
             # point-to-point ICP on sparse ring-structured sweeps keeps a few decimetres of bias (the CPU oracle lands on the same
             # transform: tests/test_gpu_voxel_knn_iss.py); reported for orientation, not a parity gate
             out[tag]["median_T_error_vs_truth_local_share"] = float(np.median(errs))
+        if world == 1:
+            # the per-pair path on the same contexts (what round 2 shipped), and bitwise agreement of the two
+            os.environ["PCR_BATCH_PER_PAIR"] = "1"
+            try:
+                el_pp, res_pp = timed(kw, 2)
+            finally:
+                del os.environ["PCR_BATCH_PER_PAIR"]
+            out[tag]["per_pair_path"] = {"seconds": el_pp, "pairs_per_s": BATCH_PAIRS / el_pp,
+                                         "results_bitwise_equal_to_fused": bool(all(np.array_equal(a["T"], b["T"]) and a["iters"] == b["iters"]
+                                                                                    for a, b in zip(res, res_pp)))}
+            # dominant kernel of the fused path, HIP events around every launch of ONE sub-batch stream (untimed, profiled run)
+            ctx0 = batch._pooled_contexts(dev_id, 1)[0]
+            ctx0.profile(True)
+            n_prof = min(32, hi - lo)
+            batch.native_register_share(pairs[lo:lo + n_prof], device=dev_id, streams=1, **kw)
+            ms, passes = ctx0.profile_read()
+            ctx0.profile(False)
+            if passes:
+                k_us = [1e3 * m / passes for m in ms[:3]]
+                algo = 40.0 * n_prof * BATCH_POINTS     # 16 B query + 16 B target + 8 B result per correspondence
+                out[tag]["roofline"] = {"bound": "hbm", "kernel": "batch_pass_kernel", "achieved": algo / (k_us[0] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": algo / (k_us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                        "pairs_per_launch": n_prof, "passes_profiled": passes,
+                                        "kernel_us": {"batch_pass_kernel": k_us[0], "batch_drain_kernel": k_us[1], "batch_finish_kernel": k_us[2]},
+                                        "note": "one launch serves every pair of a sub-batch; VALU-issue / latency bound like grid_pass_kernel, "
+                                                "rocprofv3 stats of the whole batch in profiles/r03_batch_*_kernel_stats.csv"}
     # algorithmic HBM bytes of the batch: both clouds of every pair as 16-B records
     out["algorithmic_bytes"] = BATCH_PAIRS * 2 * BATCH_POINTS * 16
     return out
+
+
+def config3_leg(pkg, ctx, src, tgt):
+    """BASELINE configs[2]: 0.2 m voxel filter (Pca_and_Voxel_filter/voxel_filter.py:10-68 as called at :87-90) of both
+    120k clouds, device resident, then point-to-point ICP on the filtered clouds (Registration/main.py:211)."""
+    ds0, dt0 = pkg.DeviceCloud.upload(src, ctx), pkg.DeviceCloud.upload(tgt, ctx)
+    pkg.voxel_filter_device(ds0, 0.2).free()   # warm
+    ctx.sync()
+    reps = 10
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    outs = [pkg.voxel_filter_device(ds0, 0.2) for _ in range(reps)]
+    dev_ms = ctx.timer_stop_ms() / reps
+    wall_ms = 1e3 * (time.perf_counter() - t0) / reps
+    rows_s = outs[0].n
+    for o in outs[1:]:
+        o.free()
+    dsv, dtv = outs[0], pkg.voxel_filter_device(dt0, 0.2)
+    rows_t = dtv.n
+    t0 = time.perf_counter()
+    index = pkg.TargetIndex(dtv, ctx=ctx)
+    ctx.sync()
+    build_ms = 1e3 * (time.perf_counter() - t0)
+    dtv.free()
+    pts_s = dsv.download()
+    run_icp_steps(pkg, index, pts_s, 10, ctx)
+    k = 50
+    t0 = time.perf_counter()
+    r = run_icp_steps(pkg, index, pts_s, k, ctx, sd=dsv.prepare(index))
+    el = time.perf_counter() - t0
+    # SURVEY 8d: 16 B in + 8 B key out per input point + 24 B per output voxel
+    algo = 24.0 * len(src) + 24.0 * rows_s
+    res = {"leaf_m": 0.2, "points_in": [int(len(src)), int(len(tgt))], "rows_out": [int(rows_s), int(rows_t)],
+           "voxel_filter_ms": wall_ms, "voxel_filter_device_ms": dev_ms, "index_build_ms": build_ms,
+           "icp_ms_per_iter": 1e3 * el / k, "icp_device_ms_per_iter": r["device_ms"] / r["iters"],
+           "correspondences_per_s": rows_s * k / el,
+           "roofline": {"bound": "hbm", "kernel": "voxel filter, all launches of one call (HIP events on the library's stream)",
+                        "achieved": algo / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "algorithmic_bytes": algo},
+           "roofline_icp": {"bound": "hbm", "kernel": "grid_pass_kernel", "achieved": 40.0 * rows_s / (r["device_ms"] / r["iters"] * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 40.0 * rows_s / (r["device_ms"] / r["iters"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "note": "40 B per correspondence (SURVEY 8d) over the device time of one iteration; cache resident, latency bound"}}
+    index.free()
+    ds0.free()
+    dt0.free()
+    return res
+
+
+def config5_leg(pkg, ctx):
+    """BASELINE configs[4]: 1 M-point synthetic scan (8 KITTI-shaped frames of one world): ISS keypoints with radius-NN
+    covariance (Keypoint_detection_ISS/ISS.py:35-73) and a coarse-to-fine ICP that ends on 1 M x 1 M points."""
+    syn = pkg.synthetic
+    poses = [syn.rigid_transform((0, 0, 1), 0.02 * i, (3.0 * i, 0.2 * i, 0)) for i in range(8)]
+    frames = [syn.kitti_like_scan(125000, seed=50 + i, sensor_pose=P) for i, P in enumerate(poses)]
+    world = np.concatenate([f.astype(np.float64) @ P[:3, :3].T + P[:3, 3] for f, P in zip(frames, poses)])
+    radius = 0.09    # mean neighbour count ~ 38 (SURVEY 8d: k ~ 40)
+    cloud = pkg.DeviceCloud.upload(world, ctx)
+    pkg.iss_keypoints(cloud, radius=radius, non_max_radius=radius, iss_count=20)   # warm
+    ctx.sync()
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    kp, lam, counts = pkg.iss_keypoints(cloud, radius=radius, non_max_radius=radius, iss_count=20, return_details=True)
+    iss_wall = time.perf_counter() - t0
+    iss_dev_ms = ctx.timer_stop_ms()
+    cloud.free()
+    T_off = syn.rigid_transform((0.05, 0.0, 1.0), np.deg2rad(3.0), (0.8, -0.4, 0.02))
+    src = (world - T_off[:3, 3]) @ T_off[:3, :3]
+    src = src + np.random.default_rng(7).normal(0, 0.01, src.shape)
+    t0 = time.perf_counter()
+    T, logs = pkg.coarse_to_fine_icp(src, world, leaves=(2.0, 0.5, 0.0), max_iteration=30)
+    c2f_wall = time.perf_counter() - t0
+    # steady-state iteration at 1 M x 1 M, inputs resident
+    index = pkg.TargetIndex(pkg.DeviceCloud.upload(world, ctx), ctx=ctx)
+    r = run_icp_steps(pkg, index, src, 20, ctx)
+    index.free()
+    algo = 52.0 * len(world)   # SURVEY 8d: 52 B per point (two passes over the records + counts + eigenvalues out)
+    return {"points": int(len(world)), "iss_radius_m": radius, "mean_neighbours": float(counts.mean()), "keypoints": len(kp),
+            "iss_ms": 1e3 * iss_wall, "iss_device_ms_incl_readback": iss_dev_ms,
+            "coarse_to_fine_icp_s": c2f_wall, "coarse_to_fine_levels": [{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in lg.items()} for lg in logs],
+            "T_error_vs_truth_max_abs": float(np.abs(T - T_off).max()),
+            "icp_1m_ms_per_iter": r["device_ms"] / r["iters"], "icp_1m_correspondences_per_s": len(world) / (r["device_ms"] / r["iters"] * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": "pcr_iss, all launches + the lambda/count read-back (HIP events on the library's stream)",
+                         "achieved": algo / (iss_dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo / (iss_dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": algo},
+            "roofline_icp": {"bound": "hbm", "kernel": "grid_pass_kernel + grid_drain_kernel (two launches per pass above 131 072 points)",
+                             "achieved": 40.0 * len(world) / (r["device_ms"] / r["iters"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": 40.0 * len(world) / (r["device_ms"] / r["iters"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
 
 
 def main():
@@ -268,7 +399,8 @@ def main():
     ap.add_argument("--no-brute", action="store_true", help="skip the brute-force MFMA leg")
     ap.add_argument("--in-flight", type=int, default=4, help="pairs in flight for the supplementary concurrent leg (0 = skip)")
     ap.add_argument("--no-batch", action="store_true", help="skip the batch256 block (BASELINE configs[3])")
-    ap.add_argument("--batch-streams", type=int, default=8, help="pairs in flight per GPU in the batch256 block (contexts = native worker threads)")
+    ap.add_argument("--batch-streams", type=int, default=8, help="contexts (= native worker threads, one sub-batch in flight each) per GPU in the batch256 block")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config3 / config5 blocks (BASELINE configs[2] and configs[4])")
     a = ap.parse_args()
 
     if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
@@ -444,6 +576,9 @@ def main():
                              "dtype": "f64 (v_mfma_f64_16x16x4_f64)"},
             }
             ib.free()
+        if world == 1 and a.nn == "grid" and not a.no_configs and a.points == N_POINTS:
+            line["config3"] = config3_leg(pkg, ctx, src, tgt)
+            line["config5"] = config5_leg(pkg, ctx)
         if world == 1 and a.nn == "grid" and a.in_flight > 1:
             line["concurrent_pairs"] = concurrent_leg(pkg, dev_id, src, tgt, a.in_flight, min(a.steps, 100))
         if world == 1 and not a.no_cpu:

@@ -136,7 +136,7 @@ typedef struct pcr_icp_result {
     double r_diff[PCR_ICP_MAX_LOG]; /* log["R_diff"], icp_template.py:189 */
     double t_diff[PCR_ICP_MAX_LOG]; /* log["t_diff"], icp_template.py:190 */
     double device_ms;      /* HIP-event time of the whole loop on the ctx stream        */
-    double nn_kernel_ms;   /* sum of HIP-event times of the correspondence kernel       */
+    double nn_kernel_ms;   /* sum of HIP-event times of the pass kernels; 0 unless pcr_profile_enable(ctx, 1) (host loop: always) */
     int32_t nn_launches;   /* launches of the correspondence kernel                     */
     int32_t reserved;
 } pcr_icp_result;

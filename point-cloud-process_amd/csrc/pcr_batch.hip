@@ -28,8 +28,6 @@
 #include "pcr_grid_dev.h"
 #include "pcr_icp_step.h"
 
-namespace {
-
 constexpr int SLOT = 256;                 // records per block of the set-up kernels; cloud slots are whole blocks
 constexpr unsigned int MIN_CAP = 256;     // smallest table of the pools: every block of 256 pool slots belongs to one table
 constexpr unsigned long long MORTON_BIAS3 = 7ull << 60;   // spread21(PCR_COORD_BIAS) on x, y and z
@@ -228,7 +226,7 @@ batch_init_tables_kernel(pcr_cell_slot* __restrict__ cell_pool, pcr_block_slot* 
     }
 }
 
-__device__ inline unsigned int slot_find_or_insert(pcr_cell_slot* tab, unsigned int mask, unsigned long long key, unsigned int h) {
+__device__ inline unsigned int batch_slot_find_or_insert(pcr_cell_slot* tab, unsigned int mask, unsigned long long key, unsigned int h) {
     unsigned int b = h & mask;
     for (unsigned int probe = 0; probe <= mask; ++probe) {
         for (unsigned int k = 0; k < 4; ++k) {
@@ -263,7 +261,7 @@ batch_insert_cells_kernel(const unsigned long long* __restrict__ keys, const bat
         if (start || end) {
             const unsigned int X = compact21(ck), Y = compact21(ck >> 1), Z = compact21(ck >> 2);
             pcr_cell_slot* tab = const_cast<pcr_cell_slot*>(gv->table[l]);
-            const unsigned int h = slot_find_or_insert(tab, gv->mask[l], cell_pack(X, Y, Z), cell_hash(X, Y, Z));
+            const unsigned int h = batch_slot_find_or_insert(tab, gv->mask[l], cell_pack(X, Y, Z), cell_hash(X, Y, Z));
             if (h != 0xffffffffu) {
                 if (start) tab[h].start = (unsigned int)li;
                 if (end) tab[h].end = (unsigned int)(li + 1);
@@ -313,6 +311,8 @@ batch_insert_blocks_kernel(const pcr_cell_slot* __restrict__ cell_pool, const un
         atomicMin(&bt[b].start, c.start);
     }
 }
+
+namespace {
 
 unsigned int next_pow2_host(unsigned long long v) {
     unsigned long long p = 1;
@@ -586,6 +586,7 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     const auto t_enq = now();
     int enq = 0;
     int chunk = params->min_iter > 2 ? params->min_iter : 2;
+    if (ctx->profile) chunk = 1;   // per-launch HIP events: a pass behind the last stop would log empty kernels
     unsigned int* const h_run = (unsigned int*)ctx->h_pinned;
     while (enq < params->max_iter) {
         if (chunk > params->max_iter - enq) chunk = params->max_iter - enq;
@@ -596,7 +597,7 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
         PCR_HIP(ctx, hipMemcpyAsync(h_run, d_running + (enq - 1), 4, hipMemcpyDeviceToHost, st));
         PCR_HIP(ctx, hipStreamSynchronize(st));
         if (*h_run == 0) break;
-        chunk *= 2;
+        if (!ctx->profile) chunk *= 2;
     }
     PCR_HIP(ctx, hipEventRecord(ctx->ev1, st));
     const auto t_icp = now();
@@ -666,7 +667,9 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
     int64_t sub = 1;
     if (fused) {
         const char* s = getenv("PCR_BATCH_SUB");
-        sub = s ? atoll(s) : (n_pairs + 2 * n_ctx - 1) / (2 * n_ctx);
+        // (256 pairs x 20 000 points on 8 contexts, pairs/s: 16 per sub-batch 28-32 k, 32: 37-39 k, 64: 34 k)
+        sub = s ? atoll(s) : (n_pairs + n_ctx - 1) / n_ctx;
+        if (!s && sub > 64) sub = 64;
         if (sub < 4) sub = n_pairs < 4 ? n_pairs : 4;
         if (sub > 256) sub = 256;
     }
@@ -676,7 +679,7 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
     if (!status) { status_own.assign((size_t)n_pairs, 0); status = status_own.data(); }
     std::atomic<int64_t> next(0);
     std::atomic<int> hard_error(PCR_OK);
-    static const bool timing = getenv("PCR_BATCH_TIMING") != nullptr;
+    const bool timing = getenv("PCR_BATCH_TIMING") != nullptr;   // read per call
     batch_timing tm;
     for (auto& v : tm.ns) v = 0;
     const auto wall0 = std::chrono::steady_clock::now();

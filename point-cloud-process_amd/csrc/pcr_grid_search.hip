@@ -2106,7 +2106,8 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     pa.la = la;
     pcr_xform xi;
     pcr_xform_from_T(nullptr, &xi);
-    int enq = 0, launches = 0;
+    int enq = 0;
+    const double prof_before = ctx->prof_ms[0] + ctx->prof_ms[1] + ctx->prof_ms[2] + ctx->prof_ms[3];
     // chunk schedule: what is known to run (min_iter) in one go, otherwise 2, 4, 8, ... (the reference's thresholds
     // usually stop after 1-3 iterations; a no-op pass costs three empty launches)
     int chunk = params->min_iter > 2 ? params->min_iter : 2;
@@ -2152,7 +2153,6 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             pcr_prof_mark(ctx, 3);
             pcr_prof_mark(ctx, 4);
             pcr_prof_finish(ctx);   // per-kernel HIP events (profiling only: one event sync per pass)
-            ++launches;
         }
         enq += chunk;
         if (rc) break;
@@ -2181,7 +2181,8 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     res->mean_d2 = h_st->mean_d2;
     for (int i = 0; i < h_st->it && i < PCR_ICP_MAX_LOG; ++i) { res->r_diff[i] = h_st->r_diff[i]; res->t_diff[i] = h_st->t_diff[i]; }
     res->nn_launches = h_st->passes;
-    (void)launches;
+    // per-pass kernel time (HIP events around the pass's launches): only measured while pcr_profile_enable is on
+    res->nn_kernel_ms = ctx->profile ? (ctx->prof_ms[0] + ctx->prof_ms[1] + ctx->prof_ms[2] + ctx->prof_ms[3]) - prof_before : 0.0;
     memcpy(res->T_total, h_st->T_total, sizeof(double) * 16);
     if (la.compat) memcpy(res->T, T_cur, sizeof(T_cur));
     else memcpy(res->T, h_st->T_total, sizeof(double) * 16);
@@ -2397,11 +2398,17 @@ int pcr_grid_batch_pass(pcr_ctx* ctx, const pcr_batch_pass_args* a, unsigned int
     static const int rounds_env = getenv("PCR_BATCH_WT_ROUNDS") ? atoi(getenv("PCR_BATCH_WT_ROUNDS")) : 0;
     const unsigned int pcap = (unsigned int)WT_PR * (rounds_env > 0 ? rounds_env : WT_ROUNDS_LARGE);
     static const bool no_prev = getenv("PCR_NO_PREV") != nullptr;
+    pcr_prof_mark(ctx, 0);   // (pcr_profile_enable: HIP events around the three launches; slots 0..2 of pcr_profile_read)
     hipLaunchKernelGGL(batch_pass_kernel, dim3(a->n_tiles / 4), dim3(256), 0, ctx->stream, *a, wtile_xcd_remap(), pcap, pass_id, (pass_id > 0 && !no_prev) ? 1 : 0);
+    pcr_prof_mark(ctx, 1);
     const long long want = (long long)a->n_tiles * WT_Q / 4;
     const int g3 = (int)(want < 8ll * ctx->cu_count ? (want < 1 ? 1 : want) : 8ll * ctx->cu_count);
     hipLaunchKernelGGL(batch_drain_kernel, dim3(g3), dim3(256), 0, ctx->stream, *a);
+    pcr_prof_mark(ctx, 2);
     hipLaunchKernelGGL(batch_finish_kernel, dim3((a->n_pairs + 3) / 4), dim3(256), 0, ctx->stream, *a, pass_id);
+    pcr_prof_mark(ctx, 3);
+    pcr_prof_mark(ctx, 4);
     PCR_HIP(ctx, hipGetLastError());
+    pcr_prof_finish(ctx);
     return PCR_OK;
 }

@@ -182,6 +182,64 @@ def test_register_batch_unequal_pairs_match_serial(pcp, syn):
         assert np.array_equal(a["T"], b["T"])
 
 
+def test_icp_batch_fused_stages_bitwise_equal_per_pair_path(pcp, syn, monkeypatch):
+    """pcr_icp_batch runs a share in fused stages (one launch per stage for all pairs of a sub-batch: csrc/pcr_batch.hip); with
+    PCR_BATCH_PER_PAIR=1 it runs upload -> index build -> pcr_icp per pair.  Unequal pairs (40 .. 25 000 points, given and
+    default T0, one pair that finds no association at all: main.py:125-127), three stopping rules, several sub-batch sizes
+    and worker counts: every field of every result must agree BIT FOR BIT."""
+    batch = __import__("importlib").import_module("point-cloud-process_amd.batch")
+    rng = np.random.default_rng(5)
+    pairs = []
+    for i in range(14):
+        n = int(rng.choice([40, 600, 3000, 12000, 25000]))
+        s, t, _ = syn.perturbed_pair(n, seed=300 + i, angle_deg=float(rng.uniform(0.5, 6.0)), t=tuple(rng.uniform(-0.8, 0.8, 3) * [1, 1, 0.1]))
+        pairs.append((s, t, None if i % 3 else syn.rigid_transform((0, 0, 1), 0.01, (0.05, 0, 0))))
+    pairs.append((pairs[1][0] + np.float32(500.0), pairs[1][1], None))
+    keys = ("iters", "status", "n_assoc", "cost", "mean_d2")
+    for kw in (dict(mode="compat"), dict(mode="total", max_iter=40, r_thres=1e-4, t_thres=1e-4), dict(mode="total", max_iter=3, r_thres=1e-9, t_thres=1e-9)):
+        monkeypatch.setenv("PCR_BATCH_PER_PAIR", "1")
+        ref = batch.native_register_share(pairs, device=0, streams=1, **kw)
+        monkeypatch.setenv("PCR_BATCH_PER_PAIR", "0")
+        assert ref[-1]["status"] == 1 and ref[-1]["iters"] == 0          # PCR_E_TOO_FEW_ASSOC: soft, the batch goes on
+        assert len({r["iters"] for r in ref}) >= 2 or kw.get("max_iter") == 3
+        for sub, streams in ((4, 1), (5, 3), (64, 2)):
+            monkeypatch.setenv("PCR_BATCH_SUB", str(sub))
+            got = batch.native_register_share(pairs, device=0, streams=streams, **kw)
+            for i, (a, b) in enumerate(zip(ref, got)):
+                assert all(a[k] == b[k] for k in keys), (kw, sub, i, {k: (a[k], b[k]) for k in keys})
+                assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["T_total"], b["T_total"]), (kw, sub, i)
+    monkeypatch.delenv("PCR_BATCH_SUB")
+
+
+def test_icp_batch_bad_pairs_do_not_poison_the_batch(pcp, syn):
+    """A NaN coordinate, an empty cloud: that pair's status is a hard error (the call returns it), every other pair of the batch
+    still gets its result (per-pair failure must not poison a batch)."""
+    import ctypes as C
+
+    batch = __import__("importlib").import_module("point-cloud-process_amd.batch")
+    L = pcp._lib
+    good = [syn.perturbed_pair(3000, seed=400 + i)[:2] for i in range(5)]
+    nan_src = good[1][0].copy()
+    nan_src[17, 1] = np.nan
+    clouds = [(good[0][0], good[0][1]), (nan_src, good[1][1]), (good[2][0], good[2][1]), (np.zeros((0, 3), np.float32), good[3][1]), (good[4][0], good[4][1])]
+    ref = batch.native_register_share([(s, t, None) for s, t in good], device=0, streams=2)
+    n = len(clouds)
+    parr = np.zeros(n, dtype=batch._PAIR_DT)
+    for i, (s, t) in enumerate(clouds):
+        parr[i] = (s.ctypes.data if len(s) else 0, s.shape[0], 3, t.ctypes.data, t.shape[0], 3, 0)
+    p = L.IcpParams()
+    L.lib().pcr_icp_default_params(C.byref(p))
+    res = np.zeros(n, dtype=batch._RESULT_DT)
+    status = np.zeros(n, dtype=np.int32)
+    ctxs = batch._pooled_contexts(0, 2)
+    handles = (C.c_void_p * 2)(*[c.handle for c in ctxs])
+    rc = L.lib().pcr_icp_batch(handles, 2, parr.ctypes.data_as(C.POINTER(L.Pair)), n, C.byref(p), res.ctypes.data_as(C.POINTER(L.IcpResult)), L.iptr(status))
+    assert rc < 0                                     # the first hard error is the call's return value
+    assert status[1] == L.PCR_E_INVALID and status[3] == L.PCR_E_EMPTY
+    for i in (0, 2, 4):
+        assert status[i] == 0 and np.array_equal(res["T"][i].reshape(4, 4), ref[i]["T"]) and res["iters"][i] == ref[i]["iters"]
+
+
 def test_icp_batch_native_entry_point(pcp, oracle, syn):
     """pcr_icp_batch (the pair loop of Registration/main.py:190-216 as one C call, native worker threads): results come back in
     pair order whatever thread ran them, equal the reference semantics (compat goldens' oracle), an empty batch is a no-op and a
