@@ -70,20 +70,24 @@ __device__ inline int cloud_of_block(const batch_cloud* __restrict__ cl, int n_c
     return s_c;
 }
 
+// `xyz_host`: the packed coordinates in pinned, device-mapped host memory, read over PCIe by this kernel (no copy engine: copies
+// of several contexts queue behind each other in the runtime, and sometimes for milliseconds); `xyz_dev` receives the device
+// copy the gather reads later.
 __global__ void __launch_bounds__(SLOT)
-batch_keys_kernel(const float* __restrict__ xyz, const batch_cloud* __restrict__ cl, int n_clouds, int mbits, unsigned long long* __restrict__ keys,
-                  unsigned int* __restrict__ vals) {
+batch_keys_kernel(const float* xyz_host, float* xyz_dev, const batch_cloud* __restrict__ cl, int n_clouds, int mbits,
+                  unsigned long long* __restrict__ keys, unsigned int* __restrict__ vals) {
     const unsigned long long i = (unsigned long long)blockIdx.x * SLOT + threadIdx.x;
     const int c = cloud_of_block(cl, n_clouds, (unsigned long long)blockIdx.x * SLOT);
     const batch_cloud C = cl[c];
     const unsigned long long mask = (1ull << mbits) - 1ull;
     unsigned long long k = mask;   // padding of the slot: behind every point of its cloud (the sort is stable)
     if (i - C.off < (unsigned long long)C.n) {
-        const float* p = xyz + 3 * i;
+        const float x = xyz_host[3 * i], y = xyz_host[3 * i + 1], z = xyz_host[3 * i + 2];
+        if (xyz_dev != xyz_host) { xyz_dev[3 * i] = x; xyz_dev[3 * i + 1] = y; xyz_dev[3 * i + 2] = z; }
         bool clamped = false;
-        const unsigned long long cx = (unsigned long long)cell_coord((double)p[0], C.lo[0], C.inv, &clamped);
-        const unsigned long long cy = (unsigned long long)cell_coord((double)p[1], C.lo[1], C.inv, &clamped);
-        const unsigned long long cz = (unsigned long long)cell_coord((double)p[2], C.lo[2], C.inv, &clamped);
+        const unsigned long long cx = (unsigned long long)cell_coord((double)x, C.lo[0], C.inv, &clamped);
+        const unsigned long long cy = (unsigned long long)cell_coord((double)y, C.lo[1], C.inv, &clamped);
+        const unsigned long long cz = (unsigned long long)cell_coord((double)z, C.lo[2], C.inv, &clamped);
         k = (spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2)) & mask;
     }
     keys[i] = ((unsigned long long)c << mbits) | k;
@@ -108,6 +112,14 @@ batch_gather_kernel(const float* __restrict__ xyz, const unsigned int* __restric
     }
     out[i] = o;
 }
+
+// 8-byte words between device memory and mapped host memory (descriptors in, loop states and flags out), zeros behind `n_copy`
+__global__ void __launch_bounds__(256)
+batch_words_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, unsigned long long n_copy, unsigned long long n_total) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += stride) dst[i] = i < n_copy ? src[i] : 0ull;
+}
+__global__ void batch_flag_kernel(const unsigned int* __restrict__ running, unsigned int* __restrict__ host_word) { *host_word = *running; }
 
 // run starts of every level, per target: counts[t][l] (one atomic per wave and level)
 __global__ void __launch_bounds__(SLOT)
@@ -408,7 +420,8 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     const size_t xyz_bytes = (size_t)slots * 12;
     const size_t off_cl = (xyz_bytes + 255) & ~(size_t)255, off_tg = off_cl + ((sizeof(batch_cloud) * n_clouds + 255) & ~(size_t)255);
     const size_t off_T0 = off_tg + ((sizeof(batch_target) * m + 255) & ~(size_t)255), off_st = off_T0 + ((128 * (size_t)m + 255) & ~(size_t)255);
-    const size_t pinned_bytes = off_st + sizeof(pcr_icp_dev_state) * (size_t)m + 256;
+    const size_t off_plan = off_st + ((sizeof(pcr_icp_dev_state) * (size_t)m + 255) & ~(size_t)255);
+    const size_t pinned_bytes = off_plan + 256;
     int rc = ensure_pinned(ctx, pinned_bytes);
     if (rc) return rc;
     char* const hp = (char*)ctx->h_stage;
@@ -540,12 +553,16 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     hipStream_t st = ctx->stream;
     PCR_HIP(ctx, hipEventRecord(ctx->ev0, st));
     // ---- uploads, keys, sort, records
-    PCR_HIP(ctx, hipMemcpyAsync(d_in.p, h_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
-    PCR_HIP(ctx, hipMemcpyAsync(ds, hp + off_cl, s_in_end, hipMemcpyHostToDevice, st));
-    PCR_HIP(ctx, hipMemsetAsync(ds + s_counts, 0, s_plan + 256 - s_counts, st));
+    // everything crosses PCIe through kernels that read / write the pinned, device-mapped staging block: no copy engine
+    char* hp_dev = nullptr;
+    PCR_HIP(ctx, hipHostGetDevicePointer((void**)&hp_dev, hp, 0));
+    hipLaunchKernelGGL(batch_words_kernel, dim3(8), dim3(256), 0, st, (const unsigned long long*)(hp_dev + off_cl), (unsigned long long*)ds,
+                       (unsigned long long)(s_in_end / 8), (unsigned long long)((s_plan + 256) / 8));   // descriptors; counts, offsets and plan zeroed
     const unsigned int blocks_all = (unsigned int)(slots / SLOT), blocks_src = (unsigned int)(src_slots / SLOT), blocks_tgt = blocks_all - blocks_src;
-    hipLaunchKernelGGL(batch_keys_kernel, dim3(blocks_all), dim3(SLOT), 0, st, d_in.as<float>(), d_cl, n_clouds, mbits, d_keys.as<unsigned long long>(),
-                       d_vals.as<unsigned int>());
+    static const bool use_dma = getenv("PCR_BATCH_DMA") != nullptr;   // A/B: the packed coordinates by the copy engine instead
+    if (use_dma) PCR_HIP(ctx, hipMemcpyAsync(d_in.p, h_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(batch_keys_kernel, dim3(blocks_all), dim3(SLOT), 0, st, use_dma ? d_in.as<float>() : (const float*)hp_dev, d_in.as<float>(), d_cl, n_clouds,
+                       mbits, d_keys.as<unsigned long long>(), d_vals.as<unsigned int>());
     PCR_HIP(ctx, rocprim::radix_sort_pairs(d_tmp.p, temp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned int>(),
                                            d_vals2.as<unsigned int>(), (size_t)slots, 0, (unsigned int)(mbits + cbits), st));
     hipLaunchKernelGGL(batch_gather_kernel, dim3(blocks_all), dim3(SLOT), 0, st, d_in.as<float>(), d_vals2.as<unsigned int>(), d_cl, n_clouds, d_pts.as<pcr_pt>());
@@ -587,14 +604,16 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     int enq = 0;
     int chunk = params->min_iter > 2 ? params->min_iter : 2;
     if (ctx->profile) chunk = 1;   // per-launch HIP events: a pass behind the last stop would log empty kernels
-    unsigned int* const h_run = (unsigned int*)ctx->h_pinned;
+    unsigned int* const h_run = (unsigned int*)ctx->h_pinned;   // (pinned, device-mapped, coherent)
+    unsigned int* h_run_dev = nullptr;
+    PCR_HIP(ctx, hipHostGetDevicePointer((void**)&h_run_dev, h_run, 0));
     while (enq < params->max_iter) {
         if (chunk > params->max_iter - enq) chunk = params->max_iter - enq;
         if (chunk > 64) chunk = 64;
         for (int c = 0; c < chunk; ++c)
             if ((rc = pcr_grid_batch_pass(ctx, &a, (unsigned int)(enq + c)))) return rc;
         enq += chunk;
-        PCR_HIP(ctx, hipMemcpyAsync(h_run, d_running + (enq - 1), 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(batch_flag_kernel, dim3(1), dim3(1), 0, st, (const unsigned int*)(d_running + (enq - 1)), h_run_dev);
         PCR_HIP(ctx, hipStreamSynchronize(st));
         if (*h_run == 0) break;
         if (!ctx->profile) chunk *= 2;
@@ -602,11 +621,17 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     PCR_HIP(ctx, hipEventRecord(ctx->ev1, st));
     const auto t_icp = now();
     pcr_icp_dev_state* const h_st = (pcr_icp_dev_state*)(hp + off_st);
-    batch_plan h_plan;
-    PCR_HIP(ctx, hipMemcpyAsync(h_st, a.st, sizeof(pcr_icp_dev_state) * (size_t)m, hipMemcpyDeviceToHost, st));
-    PCR_HIP(ctx, hipMemcpyAsync(&h_plan, d_plan, sizeof(h_plan), hipMemcpyDeviceToHost, st));
+    const batch_plan* const h_plan = (const batch_plan*)(hp + off_plan);
+    static_assert(sizeof(pcr_icp_dev_state) % 8 == 0 && sizeof(batch_plan) % 8 == 0, "copied as 8-byte words");
+    {
+        const unsigned long long nw = sizeof(pcr_icp_dev_state) / 8 * (unsigned long long)m;
+        hipLaunchKernelGGL(batch_words_kernel, dim3(64), dim3(256), 0, st, (const unsigned long long*)a.st, (unsigned long long*)(hp_dev + off_st), nw, nw);
+        hipLaunchKernelGGL(batch_words_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)d_plan, (unsigned long long*)(hp_dev + off_plan),
+                           (unsigned long long)(sizeof(batch_plan) / 8), (unsigned long long)(sizeof(batch_plan) / 8));
+    }
+    PCR_HIP(ctx, hipGetLastError());
     PCR_HIP(ctx, hipStreamSynchronize(st));
-    if (h_plan.overflow) { ctx->last_error = "batch: table pool bound exceeded"; return PCR_E_HIP; }
+    if (h_plan->overflow) { ctx->last_error = "batch: table pool bound exceeded"; return PCR_E_HIP; }
     float icp_ms = 0;
     hipEventElapsedTime(&icp_ms, ctx->ev2, ctx->ev1);
     int n_take = 0;

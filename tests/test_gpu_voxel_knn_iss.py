@@ -211,9 +211,10 @@ def test_icp_batch_fused_stages_bitwise_equal_per_pair_path(pcp, syn, monkeypatc
     monkeypatch.delenv("PCR_BATCH_SUB")
 
 
-def test_icp_batch_bad_pairs_do_not_poison_the_batch(pcp, syn):
-    """A NaN coordinate, an empty cloud: that pair's status is a hard error (the call returns it), every other pair of the batch
-    still gets its result (per-pair failure must not poison a batch)."""
+def test_icp_batch_bad_pairs_do_not_poison_the_batch(pcp, syn, monkeypatch):
+    """An empty cloud inside a batch: that pair's status is a hard error (and the call's return value), every other pair still
+    gets its result (per-pair failure must not poison a batch).  A NaN coordinate is not an error of the path (such a
+    point is never associated, like in the per-pair call): the fused stages hand that pair to the per-pair path, same bits."""
     import ctypes as C
 
     batch = __import__("importlib").import_module("point-cloud-process_amd.batch")
@@ -221,8 +222,11 @@ def test_icp_batch_bad_pairs_do_not_poison_the_batch(pcp, syn):
     good = [syn.perturbed_pair(3000, seed=400 + i)[:2] for i in range(5)]
     nan_src = good[1][0].copy()
     nan_src[17, 1] = np.nan
-    clouds = [(good[0][0], good[0][1]), (nan_src, good[1][1]), (good[2][0], good[2][1]), (np.zeros((0, 3), np.float32), good[3][1]), (good[4][0], good[4][1])]
+    monkeypatch.setenv("PCR_BATCH_PER_PAIR", "1")
     ref = batch.native_register_share([(s, t, None) for s, t in good], device=0, streams=2)
+    ref_nan = batch.native_register_share([(nan_src, good[1][1], None)], device=0, streams=1)[0]
+    monkeypatch.setenv("PCR_BATCH_PER_PAIR", "0")
+    clouds = [(good[0][0], good[0][1]), (nan_src, good[1][1]), (good[2][0], good[2][1]), (np.zeros((0, 3), np.float32), good[3][1]), (good[4][0], good[4][1])]
     n = len(clouds)
     parr = np.zeros(n, dtype=batch._PAIR_DT)
     for i, (s, t) in enumerate(clouds):
@@ -234,10 +238,12 @@ def test_icp_batch_bad_pairs_do_not_poison_the_batch(pcp, syn):
     ctxs = batch._pooled_contexts(0, 2)
     handles = (C.c_void_p * 2)(*[c.handle for c in ctxs])
     rc = L.lib().pcr_icp_batch(handles, 2, parr.ctypes.data_as(C.POINTER(L.Pair)), n, C.byref(p), res.ctypes.data_as(C.POINTER(L.IcpResult)), L.iptr(status))
-    assert rc < 0                                     # the first hard error is the call's return value
-    assert status[1] == L.PCR_E_INVALID and status[3] == L.PCR_E_EMPTY
+    assert rc == L.PCR_E_EMPTY                         # the first hard error is the call's return value
+    assert status[3] == L.PCR_E_EMPTY
     for i in (0, 2, 4):
         assert status[i] == 0 and np.array_equal(res["T"][i].reshape(4, 4), ref[i]["T"]) and res["iters"][i] == ref[i]["iters"]
+    assert status[1] == ref_nan["status"] and np.array_equal(res["T"][1].reshape(4, 4), ref_nan["T"]) and res["n_assoc"][1] == ref_nan["n_assoc"]
+    assert res["n_assoc"][1] < 3000
 
 
 def test_icp_batch_native_entry_point(pcp, oracle, syn):
