@@ -302,6 +302,40 @@ def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
     return out
 
 
+def setup_leg(pkg, ctx, src, tgt, cell):
+    """The set-up of one registration, outside the timed region of `value` (Registration/main.py:105 builds its KD-tree once per
+    pair and stops after 1-2 iterations: for the reference's own usage the set-up is most of a registration): best of 10, ms."""
+    def best(fn, free=True, reps=10):
+        t_best = None
+        for _ in range(reps):
+            ctx.sync()
+            t0 = time.perf_counter()
+            r = fn()
+            ctx.sync()
+            el = 1e3 * (time.perf_counter() - t0)
+            t_best = el if t_best is None else min(t_best, el)
+            if free:
+                r.free()
+        return t_best
+
+    up_t = best(lambda: pkg.DeviceCloud.upload(tgt, ctx))
+    dt = pkg.DeviceCloud.upload(tgt, ctx)
+    build = best(lambda: pkg.TargetIndex(dt, cell=cell, ctx=ctx))
+    index = pkg.TargetIndex(dt, cell=cell, ctx=ctx)
+    up_s = best(lambda: pkg.DeviceCloud.upload(src, ctx))
+    clouds = [pkg.DeviceCloud.upload(src, ctx) for _ in range(10)]
+    it = iter(clouds)
+    prep = best(lambda: next(it).prepare(index), free=False)
+    for c in clouds:
+        c.free()
+    one = best(lambda: pkg.icp_device(pkg.DeviceCloud.upload(src, ctx), index, np.eye(4)), free=False)
+    index.free()
+    dt.free()
+    return {"target_upload_ms": up_t, "index_build_ms": build, "source_upload_ms": up_s, "prepare_ms": prep,
+            "compat_registration_on_built_index_ms": one,
+            "note": "wall, best of 10; uploads include the host packing + bounding box and the PCIe transfer (1.44 MB per 120k cloud)"}
+
+
 def config3_leg(pkg, ctx, src, tgt):
     """BASELINE configs[2]: 0.2 m voxel filter (Pca_and_Voxel_filter/voxel_filter.py:10-68 as called at :87-90) of both
     120k clouds, device resident, then point-to-point ICP on the filtered clouds (Registration/main.py:211)."""
@@ -532,6 +566,7 @@ def main():
             "pass_kernels_ms_per_iter": rp["nn_kernel_ms"] / max(rp["nn_launches"], 1),  # from the profiled (untimed) run
             "kernel_us": kern,
             "setup_ms_not_timed": setup_ms,
+            "setup": setup_leg(pkg, ctx, src, tgt, a.cell) if a.nn == "grid" else None,
             "n_assoc_last": int(r["n_assoc"]),
             "roofline": roofline,
         }

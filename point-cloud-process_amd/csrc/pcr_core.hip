@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <chrono>
 #include <thread>
 #include "pcr_internal.h"
 
@@ -332,17 +333,70 @@ void pcr_xform_from_T(const double* T, pcr_xform* x) {
 }
 
 // ------------------------------------------------------------------ clouds
+// order-preserving map of a binary64 value to an unsigned key (monotone over all non-NaN values; every key of a real value > 0)
+__device__ static inline unsigned long long ordered_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static inline double ordered_value(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v;
+    memcpy(&v, &b, 8);
+    return v;
+}
+
+// caller's records (S = float / double, `stride` elements apart, possibly in pinned host memory read over PCIe) -> 32-byte
+// records, AND the cloud's exact bounding box on the way: six atomic maxima per block (of x, y, z and of -x, -y, -z, as ordered
+// keys: zero is the identity), the block that finishes last hands them to the host (pinned, device-mapped words) and leaves
+// the six words zero.  The upload ends with a stream synchronisation anyway, so the box costs the host nothing -- taking it in
+// a host loop cost more than the whole transfer (195 us of 250 at 120 000 points).
 template <typename S>
-__global__ void expand_cloud_kernel(const S* __restrict__ in, long long n, long long stride, pcr_pt* __restrict__ out) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const S* p = in + i * stride;
-    pcr_pt o;
-    o.x = (double)p[0];
-    o.y = (double)p[1];
-    o.z = (double)p[2];
-    o.id = i;
-    out[i] = o;
+__global__ void __launch_bounds__(256)
+expand_cloud_kernel(const S* __restrict__ in, long long n, long long stride, pcr_pt* __restrict__ out, unsigned long long* __restrict__ box,
+                    unsigned long long* __restrict__ host_box) {
+    __shared__ unsigned long long s_box[6];
+    __shared__ int s_last;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < 6) s_box[threadIdx.x] = 0ull;
+    double v[3] = {0.0, 0.0, 0.0};
+    if (i < n) {
+        const S* p = in + i * stride;
+        pcr_pt o;
+        o.x = v[0] = (double)p[0];
+        o.y = v[1] = (double)p[1];
+        o.z = v[2] = (double)p[2];
+        o.id = i;
+        out[i] = o;
+    }
+    __syncthreads();
+    unsigned long long k[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        k[a] = i < n ? ordered_key(v[a]) : 0ull;
+        k[3 + a] = i < n ? ordered_key(-v[a]) : 0ull;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned long long o = __shfl_xor(k[a], d, 64);
+            k[a] = o > k[a] ? o : k[a];
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_box[a], k[a]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) atomicMax(&box[threadIdx.x], s_box[threadIdx.x]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&box[6], 1ull) == (unsigned long long)gridDim.x - 1ull ? 1 : 0;   // ticket
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < 7) {
+        const unsigned long long w = __hip_atomic_load(&box[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 6) host_box[threadIdx.x] = w;
+        box[threadIdx.x] = 0ull;
+    }
 }
 
 __global__ void pack_xyz_kernel(const pcr_pt* __restrict__ in, long long n, double* __restrict__ out) {
@@ -377,6 +431,8 @@ static int upload_impl(pcr_ctx* ctx, const S* xyz, int64_t n, int64_t stride, pc
     if (n == 0) return PCR_E_EMPTY;
     if (n > 0x7fffffffll) return PCR_E_UNSUPPORTED;
     hipSetDevice(ctx->device);
+    static const bool timing = getenv("PCR_UPLOAD_TIMING") != nullptr;   // diagnostics: microseconds per phase to stderr
+    const auto t_0 = std::chrono::steady_clock::now();
     pcr_cloud* c = new pcr_cloud();
     c->n = n;
     int rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&c->d);
@@ -410,32 +466,38 @@ static int upload_impl(pcr_ctx* ctx, const S* xyz, int64_t n, int64_t stride, pc
         PCR_HIP(ctx, hipMemcpyAsync(d_raw, xyz, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
         d_src = (const S*)d_raw;
     }
-    // small clouds (the batched registration's 20 000-point scans): their exact bounding box is taken on the host while the
-    // data is in cache anyway -- it saves the device reduction and its read-back synchronisation in the index build and in the
-    // Morton lay-out.  (S -> double is exact; NaNs fail every comparison and poison nothing, the device path rejects them)
-    if (n <= 65536) {
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        bool finite = true;
-        for (int64_t i = 0; i < n; ++i) {
-            const S* p = xyz + i * stride;
-            for (int k = 0; k < 3; ++k) {
-                const double v = (double)p[k];
-                finite = finite && std::isfinite(v);
-                lo[k] = v < lo[k] ? v : lo[k];
-                hi[k] = v > hi[k] ? v : hi[k];
-            }
-        }
-        if (finite) {
-            c->has_bbox = true;
-            for (int k = 0; k < 3; ++k) { c->lo[k] = lo[k]; c->hi[k] = hi[k]; }
-        }
-    }
+    const auto t_1 = std::chrono::steady_clock::now();
     int block = 256;
     int grid = (int)((n + block - 1) / block);
-    hipLaunchKernelGGL(expand_cloud_kernel<S>, dim3(grid), dim3(block), 0, ctx->stream, d_src, (long long)n, (long long)stride, c->d);
+    // bounding box: d_counters words 16..29 (six 64-bit maxima + ticket, zero between uploads) -> h_pinned bytes 512..559
+    unsigned long long* const h_box = (unsigned long long*)((char*)ctx->h_pinned + 512);
+    unsigned long long* h_box_dev = nullptr;
+    PCR_HIP(ctx, hipHostGetDevicePointer((void**)&h_box_dev, h_box, 0));
+    hipLaunchKernelGGL(expand_cloud_kernel<S>, dim3(grid), dim3(block), 0, ctx->stream, d_src, (long long)n, (long long)stride, c->d,
+                       (unsigned long long*)(ctx->d_counters + 16), h_box_dev);
     PCR_HIP(ctx, hipGetLastError());
     // the staging buffer is reused by the next upload (and an unstaged copy reads caller-owned memory): finish before returning
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        // (S -> double is exact, so this is the box a binary64 reduction over the records gives; a NaN or an infinity shows up as
+        // a non-finite corner: no box then, the device reduction of pcr_cloud_bbox decides later, as before)
+        double lo[3], hi[3];
+        bool finite = true;
+        for (int k = 0; k < 3; ++k) {
+            hi[k] = ordered_value(h_box[k]);
+            lo[k] = -ordered_value(h_box[3 + k]);
+            finite = finite && std::isfinite(lo[k]) && std::isfinite(hi[k]);
+        }
+        if (finite) {
+            c->has_bbox = true;
+            for (int k = 0; k < 3; ++k) { c->lo[k] = lo[k] == 0.0 ? 0.0 : lo[k]; c->hi[k] = hi[k]; }   // (-(+0) = -0: keep +0)
+        }
+    }
+    if (timing) {
+        const auto t_2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "upload n=%lld stride=%lld: host copy + box %.1f us, expand kernel + sync %.1f us\n", (long long)n, (long long)stride,
+                std::chrono::duration_cast<std::chrono::nanoseconds>(t_1 - t_0).count() / 1e3, std::chrono::duration_cast<std::chrono::nanoseconds>(t_2 - t_1).count() / 1e3);
+    }
     if (d_raw) pcr_dev_free(ctx, d_raw, raw_bytes);
     *out = c;
     return PCR_OK;

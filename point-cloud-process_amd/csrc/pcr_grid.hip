@@ -46,40 +46,78 @@ __global__ void bbox_partial_kernel(const pcr_pt* __restrict__ pts, long long n,
     if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
-__global__ void store_view_kernel(pcr_grid_view v, pcr_grid_view* __restrict__ out) { *out = v; }
 
-__global__ void morton_keys_kernel(const pcr_pt* __restrict__ pts, long long n, double lox, double loy, double loz,
-                                   double inv, unsigned long long* __restrict__ keys, unsigned int* __restrict__ vals) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+
+
+// ------------------------------------------------------------ set-up path without fills, copies and table scans
+// Morton keys as sorted by the set-up path: only the key bits that vary over the cloud (pcr_morton_end_bit), in 32 bits when
+// they fit -- the (key, position) sort moves a third less -- else in 64.  full_key() puts the constant bias bits back.
+constexpr unsigned long long MORTON_BIAS3 = 7ull << 60;   // spread21(PCR_COORD_BIAS) on x, y and z
+template <typename K>
+__device__ static inline unsigned long long full_key(K k) { return (unsigned long long)k | MORTON_BIAS3; }
+
+template <typename K>
+__global__ void __launch_bounds__(256)
+morton_keys_var_kernel(const pcr_pt* __restrict__ pts, long long n, double lox, double loy, double loz, double inv, unsigned long long mask,
+                       K* __restrict__ keys, unsigned int* __restrict__ vals) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    pcr_pt p = pts[i];
+    const pcr_pt p = pts[i];
     bool cl = false;
-    unsigned long long cx = (unsigned long long)cell_coord(p.x, lox, inv, &cl);
-    unsigned long long cy = (unsigned long long)cell_coord(p.y, loy, inv, &cl);
-    unsigned long long cz = (unsigned long long)cell_coord(p.z, loz, inv, &cl);
-    keys[i] = spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2);
+    const unsigned long long cx = (unsigned long long)cell_coord(p.x, lox, inv, &cl);
+    const unsigned long long cy = (unsigned long long)cell_coord(p.y, loy, inv, &cl);
+    const unsigned long long cz = (unsigned long long)cell_coord(p.z, loz, inv, &cl);
+    keys[i] = (K)((spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2)) & mask);
     vals[i] = (unsigned int)i;
 }
 
-__global__ void gather_sorted_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restrict__ perm, long long n,
-                                     pcr_pt* __restrict__ out) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    out[i] = pts[perm[i]];
-}
-
-__global__ void count_cells_kernel(const unsigned long long* __restrict__ keys, long long n, int levels,
-                                   unsigned int* __restrict__ counts) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned long long k = keys[i];
-    unsigned long long kp = (i > 0) ? keys[i - 1] : 0;
+// Records into sorted order AND, for an index build (levels > 0), the number of cells of every level = run starts of key >> 6l:
+// one atomic per block and level; the block that finishes last hands the counts to the host (pinned, device-mapped words) and
+// leaves the counters zero for the next build -- no memset, no copy.
+template <typename K>
+__global__ void __launch_bounds__(256)
+gather_count_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restrict__ perm, const K* __restrict__ keys, long long n, int levels,
+                    pcr_pt* __restrict__ out, unsigned int* __restrict__ counts, unsigned int* __restrict__ host_counts) {
+    __shared__ unsigned int s_cnt[PCR_MAX_LEVELS];
+    __shared__ int s_last;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (levels > 0 && threadIdx.x < PCR_MAX_LEVELS) s_cnt[threadIdx.x] = 0;
+    if (i < n) out[i] = pts[perm[i]];
+    if (levels <= 0) return;
+    __syncthreads();
+    const unsigned long long k = i < n ? full_key(keys[i]) : 0ull, kp = (i < n && i > 0) ? full_key(keys[i - 1]) : 0ull;
     for (int l = 0; l < levels; ++l) {
-        bool start = (i == 0) || ((k >> (6 * l)) != (kp >> (6 * l)));
-        // hipcc folds these per-lane adds into one atomic per wave
-        if (start) atomicAdd(&counts[l], 1u);
+        const bool start = i < n && (i == 0 || (k >> (6 * l)) != (kp >> (6 * l)));
+        const unsigned long long b = __ballot(start);
+        if (b && (threadIdx.x & 63) == 0) atomicAdd(&s_cnt[l], (unsigned int)__popcll(b));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < levels && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&counts[15], 1u) == gridDim.x - 1 ? 1 : 0;   // ticket
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < 16) {
+        const unsigned int v = __hip_atomic_load(&counts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        host_counts[threadIdx.x] = v;
+        counts[threadIdx.x] = 0;
     }
 }
+
+// all tables of an index in one launch: cell slots all-ones, block slots {free key, start = ~0, flags = 0, counts = 0}
+__global__ void __launch_bounds__(256)
+init_pools_kernel(pcr_cell_slot* __restrict__ cell_pool, unsigned long long n_cells, pcr_block_slot* __restrict__ block_pool, unsigned long long n_blocks) {
+    typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    u2* cp = reinterpret_cast<u2*>(cell_pool);
+    for (unsigned long long i = t0; i < n_cells; i += stride) cp[i] = u2{~0ull, ~0ull};
+    u2* bp = reinterpret_cast<u2*>(block_pool);
+    for (unsigned long long i = t0; i < 2 * n_blocks; i += stride) bp[i] = (i & 1) ? u2{0ull, 0ull} : u2{PCR_EMPTY_KEY, 0x00000000ffffffffull};
+}
+
+
 
 struct pcr_tables {
     pcr_cell_slot* t[PCR_MAX_LEVELS];
@@ -100,21 +138,31 @@ __device__ static inline unsigned int slot_find_or_insert(pcr_cell_slot* tab, un
     return 0xffffffffu;  // table full: cannot happen at load factor <= 0.25
 }
 
-__global__ void insert_cells_kernel(const unsigned long long* __restrict__ keys, long long n, int levels, pcr_tables tabs) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+
+struct pcr_btables {
+    pcr_block_slot* t[PCR_MAX_LEVELS];
+    unsigned int mask[PCR_MAX_LEVELS];
+    unsigned int cap[PCR_MAX_LEVELS];
+};
+
+
+
+
+template <typename K>
+__global__ void __launch_bounds__(256)
+insert_cells_var_kernel(const K* __restrict__ keys, long long n, int levels, pcr_tables tabs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned long long k = keys[i];
-    unsigned long long kp = (i > 0) ? keys[i - 1] : 0;
-    unsigned long long kn = (i + 1 < n) ? keys[i + 1] : 0;
+    const unsigned long long k = full_key(keys[i]);
+    const unsigned long long kp = i > 0 ? full_key(keys[i - 1]) : 0ull, kn = i + 1 < n ? full_key(keys[i + 1]) : 0ull;
     for (int l = 0; l < levels; ++l) {
-        unsigned long long ck = k >> (6 * l);
-        bool start = (i == 0) || (ck != (kp >> (6 * l)));
-        bool end = (i + 1 == n) || (ck != (kn >> (6 * l)));
+        const unsigned long long ck = k >> (6 * l);
+        const bool start = (i == 0) || (ck != (kp >> (6 * l)));
+        const bool end = (i + 1 == n) || (ck != (kn >> (6 * l)));
         if (start || end) {
-            // table key = packed level-l cell coordinates (cheap to form at query time)
             const unsigned int X = compact21(ck), Y = compact21(ck >> 1), Z = compact21(ck >> 2);
             const unsigned long long pk = (unsigned long long)X | ((unsigned long long)Y << 21) | ((unsigned long long)Z << 42);
-            unsigned int h = slot_find_or_insert(tabs.t[l], tabs.mask[l], pk, cell_hash(X, Y, Z));
+            const unsigned int h = slot_find_or_insert(tabs.t[l], tabs.mask[l], pk, cell_hash(X, Y, Z));
             if (h != 0xffffffffu) {
                 if (start) tabs.t[l][h].start = (unsigned int)i;
                 if (end) tabs.t[l][h].end = (unsigned int)(i + 1);
@@ -123,31 +171,23 @@ __global__ void insert_cells_kernel(const unsigned long long* __restrict__ keys,
     }
 }
 
-struct pcr_btables {
-    pcr_block_slot* t[PCR_MAX_LEVELS];
-    unsigned int mask[PCR_MAX_LEVELS];
-    unsigned int cap[PCR_MAX_LEVELS];
-};
-
-__global__ void init_blocks_kernel(pcr_btables bt, int levels) {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int l = 0; l < levels; ++l)
-        if (i < bt.cap[l]) {
-            pcr_block_slot e;
-            e.key = PCR_EMPTY_KEY; e.start = 0xffffffffu; e.flags = 0;
-            for (int k = 0; k < 8; ++k) e.cnt[k] = 0;
-            bt.t[l][i] = e;
-        }
-}
-
-// one thread per slot of the cell tables: the cell registers itself in its 2x2x2 block
-__global__ void insert_blocks_kernel(pcr_tables tabs, pcr_btables bt, int levels) {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+// The thread at the first point of a cell's run looks its (now complete) slot up and registers the cell in its 2x2x2 block:
+// work proportional to the cells, coalesced key reads (walking every slot of every table instead -- four fifths of them
+// empty -- took 18.5 us at 120 000 points).  Thread 0 also stores the device copy of the view.
+template <typename K>
+__global__ void __launch_bounds__(256)
+insert_blocks_var_kernel(const K* __restrict__ keys, long long n, int levels, pcr_tables tabs, pcr_btables bt, pcr_grid_view v, pcr_grid_view* __restrict__ d_view) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *d_view = v;
+    if (i >= n) return;
+    const unsigned long long k = full_key(keys[i]);
+    const unsigned long long kp = i > 0 ? full_key(keys[i - 1]) : 0ull;
     for (int l = 0; l < levels; ++l) {
-        if (i >= (tabs.mask[l] + 1) * 4) continue;
-        const pcr_cell_slot c = tabs.t[l][i];
-        if (c.key == PCR_EMPTY_KEY) continue;
-        const unsigned int X = (unsigned int)(c.key & 0x1fffffull), Y = (unsigned int)((c.key >> 21) & 0x1fffffull), Z = (unsigned int)((c.key >> 42) & 0x1fffffull);
+        const unsigned long long ck = k >> (6 * l);
+        if (i != 0 && ck == (kp >> (6 * l))) break;   // not a run start here: not one on any coarser level either
+        const unsigned int X = compact21(ck), Y = compact21(ck >> 1), Z = compact21(ck >> 2);
+        unsigned int cs = 0, ce = 0;
+        if (!lookup_cell(tabs.t[l], tabs.mask[l], X, Y, Z, &cs, &ce)) continue;
         const unsigned int BX = X >> 1, BY = Y >> 1, BZ = Z >> 1;
         const int child = (int)((X & 1) | ((Y & 1) << 1) | ((Z & 1) << 2));
         const unsigned long long bk = cell_pack(BX, BY, BZ);
@@ -157,10 +197,10 @@ __global__ void insert_blocks_kernel(pcr_tables tabs, pcr_btables bt, int levels
             if (old == PCR_EMPTY_KEY || old == bk) break;
             b = (b + 1) & bt.mask[l];
         }
-        const unsigned int cnt = c.end - c.start;
+        const unsigned int cnt = ce - cs;
         if (cnt >= 0xffffu) atomicOr(&bt.t[l][b].flags, 1u);
         bt.t[l][b].cnt[child] = (unsigned short)(cnt >= 0xffffu ? 0xffffu : cnt);
-        atomicMin(&bt.t[l][b].start, c.start);
+        atomicMin(&bt.t[l][b].start, cs);
     }
 }
 
@@ -240,141 +280,157 @@ void pcr_grid_plan(const double lo[3], const double hi[3], long long n, double c
     *levels_out = levels;
 }
 
-// idx->lo/hi must already hold the target's bounding box (pcr_index_build computes it).
-int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* idx) {
-    const long long n = tgt->n;
-    const int block = 256;
-    const int grid_n = (int)((n + block - 1) / block);
+// Keys of the varying Morton bits -> stable sort of (key, position) -> records in sorted order (+ cell counts of `levels` levels
+// in ctx->h_pinned[0..levels), valid after the next stream synchronisation).  The sorted keys stay in *keys_out until sort_scratch_free.
+struct sort_scratch {
+    void *keys = nullptr, *keys2 = nullptr, *temp = nullptr;
+    unsigned int *vals = nullptr, *vals2 = nullptr;
+    size_t key_bytes = 0, temp_bytes = 0;
+    long long n = 0;
+};
+static void sort_scratch_free(pcr_ctx* ctx, sort_scratch* sc) {
+    if (sc->temp) pcr_dev_free(ctx, sc->temp, sc->temp_bytes);
+    if (sc->keys) pcr_dev_free(ctx, sc->keys, sc->key_bytes);
+    if (sc->keys2) pcr_dev_free(ctx, sc->keys2, sc->key_bytes);
+    if (sc->vals) pcr_dev_free(ctx, sc->vals, sizeof(unsigned int) * sc->n);
+    if (sc->vals2) pcr_dev_free(ctx, sc->vals2, sizeof(unsigned int) * sc->n);
+    *sc = sort_scratch();
+}
+template <typename K>
+static int morton_sort_records(pcr_ctx* ctx, const pcr_pt* in, long long n, const double lo[3], double inv, int end_bit, int levels, pcr_pt* out,
+                               sort_scratch* sc) {
     int rc;
-    double lo[3] = {idx->lo[0], idx->lo[1], idx->lo[2]}, hi[3] = {idx->hi[0], idx->hi[1], idx->hi[2]};
-    int levels = 1;
-    pcr_grid_plan(lo, hi, n, cell, &cell, &levels);
-    idx->cell = cell;
-    // ---- keys, sort, gather
-    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
-    unsigned int *d_vals = nullptr, *d_vals2 = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys2))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals2))) return rc;
-    const double inv = 1.0 / cell;
-    hipLaunchKernelGGL(morton_keys_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)tgt->d, n, lo[0], lo[1], lo[2],
-                       inv, d_keys, d_vals);
-    size_t temp_bytes = 0;
-    const int end_bit = pcr_morton_end_bit(lo, hi, inv);
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
-    void* d_temp = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
-    if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&idx->sorted))) return rc;
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)tgt->d,
-                       (const unsigned int*)d_vals2, n, idx->sorted);
-    // ---- per-level tables
-    unsigned int* d_counts = ctx->d_counters;  // 16 words at offset 0
-    PCR_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(unsigned int) * 16, ctx->stream));
-    hipLaunchKernelGGL(count_cells_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const unsigned long long*)d_keys2, n, levels,
-                       d_counts);
-    unsigned int h_counts[16];
-    PCR_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pcr_tables tabs;
-    memset(&tabs, 0, sizeof(tabs));
-    for (int l = 0; l < levels; ++l) {
-        unsigned int cap = (unsigned int)next_pow2(h_counts[l] * 4 + 4);  // slots; load factor <= 0.25
-        if (cap < 16) cap = 16;
-        idx->caps[l] = cap;
-        if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_cell_slot) * cap, (void**)&idx->tables[l]))) return rc;
-        PCR_HIP(ctx, hipMemsetAsync(idx->tables[l], 0xff, sizeof(pcr_cell_slot) * cap, ctx->stream));
-        tabs.t[l] = idx->tables[l];
-        tabs.mask[l] = cap / 4 - 1;  // buckets of 4 slots
-    }
-    hipLaunchKernelGGL(insert_cells_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const unsigned long long*)d_keys2, n, levels, tabs);
+    sc->n = n;
+    sc->key_bytes = sizeof(K) * (size_t)n;
+    if ((rc = pcr_dev_alloc(ctx, sc->key_bytes, &sc->keys)) || (rc = pcr_dev_alloc(ctx, sc->key_bytes, &sc->keys2)) ||
+        (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&sc->vals)) || (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&sc->vals2)))
+        return rc;
+    K *keys = (K*)sc->keys, *keys2 = (K*)sc->keys2;
+    const int grid_n = (int)((n + 255) / 256);
+    const unsigned long long mask = end_bit >= 64 ? ~0ull : (1ull << end_bit) - 1ull;
+    hipLaunchKernelGGL(morton_keys_var_kernel<K>, dim3(grid_n), dim3(256), 0, ctx->stream, in, n, lo[0], lo[1], lo[2], inv, mask, keys, sc->vals);
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sc->temp_bytes, keys, keys2, sc->vals, sc->vals2, (size_t)n, 0, (unsigned int)end_bit, ctx->stream));
+    if ((rc = pcr_dev_alloc(ctx, sc->temp_bytes, &sc->temp))) return rc;
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(sc->temp, sc->temp_bytes, keys, keys2, sc->vals, sc->vals2, (size_t)n, 0, (unsigned int)end_bit, ctx->stream));
+    unsigned int* h_counts_dev = nullptr;
+    if (levels > 0) PCR_HIP(ctx, hipHostGetDevicePointer((void**)&h_counts_dev, ctx->h_pinned, 0));
+    hipLaunchKernelGGL(gather_count_kernel<K>, dim3(grid_n), dim3(256), 0, ctx->stream, in, (const unsigned int*)sc->vals2, (const K*)keys2, n, levels, out,
+                       ctx->d_counters, h_counts_dev);   // d_counters[0..16): zero between builds (the last block leaves them so)
     PCR_HIP(ctx, hipGetLastError());
-    // ---- 2x2x2-block tables (one line per 8 cells for the tile stage's directory)
-    pcr_btables bt;
-    memset(&bt, 0, sizeof(bt));
-    unsigned int max_cap = 16, max_bcap = 16;
+    return PCR_OK;
+}
+
+template <typename K>
+static int grid_build_tables(pcr_ctx* ctx, pcr_index* idx, const sort_scratch* sc, int levels, const unsigned int* h_counts, const double lo[3], const double hi[3],
+                             double cell) {
+    const long long n = idx->n;
+    int rc;
+    // every level's tables in two allocations (cells, 2x2x2 blocks): one launch initialises them all
+    size_t cell_slots = 0, block_slots = 0;
     for (int l = 0; l < levels; ++l) {
+        unsigned int cap = (unsigned int)next_pow2(h_counts[l] * 4 + 4);   // slots; load factor <= 0.25
+        if (cap < 16) cap = 16;
         unsigned int bcap = (unsigned int)next_pow2(h_counts[l] * 2 + 4);  // blocks <= cells: load factor <= 0.5, usually ~0.15
         if (bcap < 16) bcap = 16;
+        idx->caps[l] = cap;
         idx->bcaps[l] = bcap;
-        if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_block_slot) * bcap, (void**)&idx->btables[l]))) return rc;
-        bt.t[l] = idx->btables[l];
-        bt.mask[l] = bcap - 1;
-        bt.cap[l] = bcap;
-        if (bcap > max_bcap) max_bcap = bcap;
-        if (idx->caps[l] > max_cap) max_cap = idx->caps[l];
+        cell_slots += cap;
+        block_slots += bcap;
     }
-    hipLaunchKernelGGL(init_blocks_kernel, dim3((max_bcap + 255) / 256), dim3(256), 0, ctx->stream, bt, levels);
-    hipLaunchKernelGGL(insert_blocks_kernel, dim3((max_cap + 255) / 256), dim3(256), 0, ctx->stream, tabs, bt, levels);
-    PCR_HIP(ctx, hipGetLastError());
-    pcr_dev_free(ctx, d_temp, temp_bytes);
-    pcr_dev_free(ctx, d_keys, sizeof(unsigned long long) * n);
-    pcr_dev_free(ctx, d_keys2, sizeof(unsigned long long) * n);
-    pcr_dev_free(ctx, d_vals, sizeof(unsigned int) * n);
-    pcr_dev_free(ctx, d_vals2, sizeof(unsigned int) * n);
-    // ---- view
+    idx->cell_pool_bytes = sizeof(pcr_cell_slot) * cell_slots;
+    idx->block_pool_bytes = sizeof(pcr_block_slot) * block_slots;
+    if ((rc = pcr_dev_alloc(ctx, idx->cell_pool_bytes, (void**)&idx->cell_pool)) || (rc = pcr_dev_alloc(ctx, idx->block_pool_bytes, (void**)&idx->block_pool)) ||
+        (rc = pcr_dev_alloc(ctx, sizeof(pcr_grid_view), (void**)&idx->d_view)))
+        return rc;
+    pcr_tables tabs;
+    pcr_btables bt;
+    memset(&tabs, 0, sizeof(tabs));
+    memset(&bt, 0, sizeof(bt));
     pcr_grid_view& v = idx->view;
     memset(&v, 0, sizeof(v));
     v.pts = idx->sorted;
     v.n = n;
     v.levels = levels;
     v.cell0 = cell;
-    v.inv_cell0 = inv;
+    v.inv_cell0 = 1.0 / cell;
     for (int k = 0; k < 3; ++k) {
         v.lo[k] = lo[k];
         v.origin[k] = 0.5 * (lo[k] + hi[k]);
     }
+    size_t co = 0, bo = 0;
     for (int l = 0; l < levels; ++l) {
+        idx->tables[l] = idx->cell_pool + co;
+        idx->btables[l] = idx->block_pool + bo;
+        co += idx->caps[l];
+        bo += idx->bcaps[l];
+        tabs.t[l] = idx->tables[l];
+        tabs.mask[l] = idx->caps[l] / 4 - 1;   // buckets of 4 slots
+        bt.t[l] = idx->btables[l];
+        bt.mask[l] = idx->bcaps[l] - 1;
+        bt.cap[l] = idx->bcaps[l];
         v.table[l] = idx->tables[l];
-        v.mask[l] = idx->caps[l] / 4 - 1;  // buckets of 4 slots
+        v.mask[l] = tabs.mask[l];
         v.btable[l] = idx->btables[l];
-        v.bmask[l] = idx->bcaps[l] - 1;
+        v.bmask[l] = bt.mask[l];
     }
-    // device copy of the view: the search kernels read it through a pointer (scalar loads of the few fields a wave
-    // needs) instead of carrying its 400 bytes in kernel-argument SGPRs
-    // (written by a one-thread kernel that takes the view as its argument: no host copy, no synchronisation)
-    if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_grid_view), (void**)&idx->d_view))) return rc;
-    hipLaunchKernelGGL(store_view_kernel, dim3(1), dim3(1), 0, ctx->stream, idx->view, idx->d_view);
+    const int grid_n = (int)((n + 255) / 256);
+    const unsigned long long words = cell_slots + 2 * block_slots;
+    int gi = (int)((words + 256 * 4 - 1) / (256 * 4));
+    if (gi > 4 * ctx->cu_count) gi = 4 * ctx->cu_count;
+    hipLaunchKernelGGL(init_pools_kernel, dim3(gi < 1 ? 1 : gi), dim3(256), 0, ctx->stream, idx->cell_pool, (unsigned long long)cell_slots, idx->block_pool,
+                       (unsigned long long)block_slots);
+    hipLaunchKernelGGL(insert_cells_var_kernel<K>, dim3(grid_n), dim3(256), 0, ctx->stream, (const K*)sc->keys2, n, levels, tabs);
+    // (the device copy of the view -- the search kernels read the few fields a wave needs through a pointer, by scalar loads,
+    // instead of carrying its 400 bytes in kernel-argument SGPRs -- is stored by thread 0 of this launch)
+    hipLaunchKernelGGL(insert_blocks_var_kernel<K>, dim3(grid_n), dim3(256), 0, ctx->stream, (const K*)sc->keys2, n, levels, tabs, bt, idx->view, idx->d_view);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
+}
+
+// idx->lo/hi must already hold the target's bounding box (pcr_index_build computes it).
+// Launches: keys, the sort's, gather + cell counts, [one synchronisation: the counts size the tables], tables' init, cells, blocks.
+int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* idx) {
+    const long long n = tgt->n;
+    int rc;
+    double lo[3] = {idx->lo[0], idx->lo[1], idx->lo[2]}, hi[3] = {idx->hi[0], idx->hi[1], idx->hi[2]};
+    int levels = 1;
+    pcr_grid_plan(lo, hi, n, cell, &cell, &levels);
+    idx->cell = cell;
+    const double inv = 1.0 / cell;
+    const int end_bit = pcr_morton_end_bit(lo, hi, inv);
+    if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&idx->sorted))) return rc;
+    sort_scratch sc;
+    const bool k32 = end_bit <= 32;
+    rc = k32 ? morton_sort_records<unsigned int>(ctx, tgt->d, n, lo, inv, end_bit, levels, idx->sorted, &sc)
+             : morton_sort_records<unsigned long long>(ctx, tgt->d, n, lo, inv, end_bit, levels, idx->sorted, &sc);
+    if (rc == PCR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->last_error = "hipStreamSynchronize (index build)"; rc = PCR_E_HIP; }
+    if (rc == PCR_OK) {
+        unsigned int h_counts[16];
+        memcpy(h_counts, ctx->h_pinned, sizeof(h_counts));
+        rc = k32 ? grid_build_tables<unsigned int>(ctx, idx, &sc, levels, h_counts, lo, hi, cell)
+                 : grid_build_tables<unsigned long long>(ctx, idx, &sc, levels, h_counts, lo, hi, cell);
+    }
+    sort_scratch_free(ctx, &sc);   // (stream-ordered with the launches above)
+    return rc;
 }
 
 int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell) {
     if (c->morton_sorted || c->n < 2) { c->morton_sorted = true; return PCR_OK; }
     const long long n = c->n;
-    const int block = 256;
-    const int grid_n = (int)((n + block - 1) / block);
     double lo[3], hi[3];
     int rc = pcr_cloud_bbox(ctx, c, lo, hi);
     if (rc) return rc;
     const double emax = fmax(hi[0] - lo[0], fmax(hi[1] - lo[1], hi[2] - lo[2]));
     if (!(cell > 0)) cell = emax > 0 ? emax / 1024.0 : 1.0;
     if (cell < emax / 262144.0) cell = emax / 262144.0;
-    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
-    unsigned int *d_vals = nullptr, *d_vals2 = nullptr;
     pcr_pt* d_out = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys2))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals2))) return rc;
     if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * n, (void**)&d_out))) return rc;
-    hipLaunchKernelGGL(morton_keys_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, n, lo[0], lo[1], lo[2],
-                       1.0 / cell, d_keys, d_vals);
-    size_t temp_bytes = 0;
     const int end_bit = pcr_morton_end_bit(lo, hi, 1.0 / cell);
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
-    void* d_temp = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0, end_bit, ctx->stream));
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, (const unsigned int*)d_vals2, n,
-                       d_out);
-    PCR_HIP(ctx, hipGetLastError());
-    pcr_dev_free(ctx, d_temp, temp_bytes);
-    pcr_dev_free(ctx, d_keys, sizeof(unsigned long long) * n);
-    pcr_dev_free(ctx, d_keys2, sizeof(unsigned long long) * n);
-    pcr_dev_free(ctx, d_vals, sizeof(unsigned int) * n);
-    pcr_dev_free(ctx, d_vals2, sizeof(unsigned int) * n);
+    sort_scratch sc;
+    rc = end_bit <= 32 ? morton_sort_records<unsigned int>(ctx, c->d, n, lo, 1.0 / cell, end_bit, 0, d_out, &sc)
+                       : morton_sort_records<unsigned long long>(ctx, c->d, n, lo, 1.0 / cell, end_bit, 0, d_out, &sc);
+    sort_scratch_free(ctx, &sc);
+    if (rc) { pcr_dev_free(ctx, d_out, sizeof(pcr_pt) * n); return rc; }
     pcr_dev_free(ctx, c->d, sizeof(pcr_pt) * n);
     c->d = d_out;
     c->morton_sorted = true;
@@ -384,13 +440,11 @@ int pcr_cloud_morton_sort(pcr_ctx* ctx, pcr_cloud* c, double cell) {
 void pcr_grid_free(pcr_ctx* ctx, pcr_index* idx) {
     if (idx->d_view) pcr_dev_free(ctx, idx->d_view, sizeof(pcr_grid_view));
     idx->d_view = nullptr;
-    pcr_dev_free(ctx, idx->sorted, sizeof(pcr_pt) * idx->n);
+    if (idx->sorted) pcr_dev_free(ctx, idx->sorted, sizeof(pcr_pt) * idx->n);
     idx->sorted = nullptr;
-    for (int l = 0; l < PCR_MAX_LEVELS; ++l) {
-        if (idx->tables[l]) pcr_dev_free(ctx, idx->tables[l], sizeof(pcr_cell_slot) * idx->caps[l]);
-        idx->tables[l] = nullptr;
-        if (idx->btables[l]) pcr_dev_free(ctx, idx->btables[l], sizeof(pcr_block_slot) * idx->bcaps[l]);
-        idx->btables[l] = nullptr;
-    }
+    if (idx->cell_pool) pcr_dev_free(ctx, idx->cell_pool, idx->cell_pool_bytes);
+    if (idx->block_pool) pcr_dev_free(ctx, idx->block_pool, idx->block_pool_bytes);
+    idx->cell_pool = nullptr;
+    idx->block_pool = nullptr;
+    for (int l = 0; l < PCR_MAX_LEVELS; ++l) idx->tables[l] = nullptr, idx->btables[l] = nullptr;   // (pointers into the pools)
 }
-

@@ -264,7 +264,9 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                                                     double* __restrict__ res_d2, unsigned long long* __restrict__ dbg,
                                                     const wt_xyz* __restrict__ prev_xyz, wt_state& S, const unsigned long long* probe_p = nullptr,
                                                     const unsigned int probe_stride = 0, const unsigned int probe_groups = 0, const unsigned int probe_total = 0) {
+#if !PCR_WT_MFMA
     typedef float f2 __attribute__((ext_vector_type(2)));
+#endif
     typedef float f4 __attribute__((ext_vector_type(4)));
     const pcr_pt* __restrict__ g_pts = as_global(gv.pts);
 #ifdef PCR_WT_DIAG   // phase stamps + "why still open" counters for scripts/wt_stamps.py: a diagnostic build only (they cost registers)

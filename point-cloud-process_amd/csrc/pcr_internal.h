@@ -71,6 +71,9 @@ struct pcr_index {
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     // GRID
     pcr_pt* sorted = nullptr;
+    pcr_cell_slot* cell_pool = nullptr;       // every level's cell table (tables[l] point into it)
+    pcr_block_slot* block_pool = nullptr;     // every level's 2x2x2-block table
+    size_t cell_pool_bytes = 0, block_pool_bytes = 0;
     pcr_cell_slot* tables[PCR_MAX_LEVELS] = {nullptr};
     unsigned int caps[PCR_MAX_LEVELS] = {0};
     pcr_block_slot* btables[PCR_MAX_LEVELS] = {nullptr};
