@@ -1554,13 +1554,17 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
             for (unsigned int i = c0; i < r0; ++i) {
                 unsigned long long* it = A.items + ((size_t)gg * A.cap + i) * 4;
                 unsigned long long w = ITEM_NONE;
+                bool arrived = false;
                 for (unsigned int spins = 0; spins < PASS_SPIN_LIMIT; ++spins) {
                     if (lane < 4) w = ld_dev(it + lane);
                     const unsigned int w3_hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), 3);
-                    if (__ballot(lane < 4 && w != ITEM_NONE && !(lane == 3 && w3_hi == POISON_HI)) == 0xfull) break;
+                    if (__ballot(lane < 4 && w != ITEM_NONE && !(lane == 3 && w3_hi == POISON_HI)) == 0xfull) { arrived = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 if (lane < 4) st_dev(it + lane, ITEM_NONE);
+                // an item that never arrived (its words would decode to query 0xffffffff) is never served: the pass is flagged
+                // failed instead, pass_finish reports PCR_E_HIP for the call
+                if (!arrived) { if (lane == 0) st_dev(root + 16, 1ull); continue; }
                 pass_serve_item(gv, L, lane, w, max_d2, A, res_pos, dbg, 59999u, t_start);
             }
         }
