@@ -27,6 +27,7 @@
 #include "pcr_internal.h"
 #include "pcr_grid_dev.h"
 #include "pcr_icp_step.h"
+#include "pcr_sort.h"
 
 constexpr int SLOT = 256;                 // records per block of the set-up kernels; cloud slots are whole blocks
 constexpr unsigned int MIN_CAP = 256;     // smallest table of the pools: every block of 256 pool slots belongs to one table
@@ -528,7 +529,7 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     {
         unsigned long long* kn = nullptr;
         unsigned int* vn = nullptr;
-        if (rocprim::radix_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, (size_t)slots, 0, (unsigned int)(mbits + cbits), ctx->stream) != hipSuccess) return PCR_E_HIP;
+        if (pcr_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, (size_t)slots, (unsigned int)(mbits + cbits), ctx->stream) != hipSuccess) return PCR_E_HIP;
     }
     // small things in one block: clouds | targets | T0s | counts | cell offsets | plan | pairs | running
     const size_t s_cl = 0, s_tg = off_tg - off_cl, s_T0 = off_T0 - off_cl, s_in_end = off_st - off_cl;   // (same layout as the pinned block)
@@ -563,8 +564,8 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     if (use_dma) PCR_HIP(ctx, hipMemcpyAsync(d_in.p, h_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(batch_keys_kernel, dim3(blocks_all), dim3(SLOT), 0, st, use_dma ? d_in.as<float>() : (const float*)hp_dev, d_in.as<float>(), d_cl, n_clouds,
                        mbits, d_keys.as<unsigned long long>(), d_vals.as<unsigned int>());
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_tmp.p, temp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned int>(),
-                                           d_vals2.as<unsigned int>(), (size_t)slots, 0, (unsigned int)(mbits + cbits), st));
+    PCR_HIP(ctx, pcr_sort_pairs(d_tmp.p, temp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned int>(),
+                                d_vals2.as<unsigned int>(), (size_t)slots, (unsigned int)(mbits + cbits), st));
     hipLaunchKernelGGL(batch_gather_kernel, dim3(blocks_all), dim3(SLOT), 0, st, d_in.as<float>(), d_vals2.as<unsigned int>(), d_cl, n_clouds, d_pts.as<pcr_pt>());
     // ---- grids of all targets
     if (blocks_tgt)

@@ -21,6 +21,7 @@
 #include <rocprim/rocprim.hpp>
 #include "pcr_internal.h"
 #include "pcr_grid_dev.h"
+#include "pcr_sort.h"
 
 // ------------------------------------------------------------ build kernels
 __global__ void bbox_partial_kernel(const pcr_pt* __restrict__ pts, long long n, double* __restrict__ part) {
@@ -309,9 +310,9 @@ static int morton_sort_records(pcr_ctx* ctx, const pcr_pt* in, long long n, cons
     const int grid_n = (int)((n + 255) / 256);
     const unsigned long long mask = end_bit >= 64 ? ~0ull : (1ull << end_bit) - 1ull;
     hipLaunchKernelGGL(morton_keys_var_kernel<K>, dim3(grid_n), dim3(256), 0, ctx->stream, in, n, lo[0], lo[1], lo[2], inv, mask, keys, sc->vals);
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sc->temp_bytes, keys, keys2, sc->vals, sc->vals2, (size_t)n, 0, (unsigned int)end_bit, ctx->stream));
+    PCR_HIP(ctx, pcr_sort_pairs(nullptr, sc->temp_bytes, keys, keys2, sc->vals, sc->vals2, (size_t)n, (unsigned int)end_bit, ctx->stream));
     if ((rc = pcr_dev_alloc(ctx, sc->temp_bytes, &sc->temp))) return rc;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(sc->temp, sc->temp_bytes, keys, keys2, sc->vals, sc->vals2, (size_t)n, 0, (unsigned int)end_bit, ctx->stream));
+    PCR_HIP(ctx, pcr_sort_pairs(sc->temp, sc->temp_bytes, keys, keys2, sc->vals, sc->vals2, (size_t)n, (unsigned int)end_bit, ctx->stream));
     unsigned int* h_counts_dev = nullptr;
     if (levels > 0) PCR_HIP(ctx, hipHostGetDevicePointer((void**)&h_counts_dev, ctx->h_pinned, 0));
     hipLaunchKernelGGL(gather_count_kernel<K>, dim3(grid_n), dim3(256), 0, ctx->stream, in, (const unsigned int*)sc->vals2, (const K*)keys2, n, levels, out,

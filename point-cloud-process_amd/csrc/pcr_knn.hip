@@ -19,6 +19,7 @@
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "pcr_grid_dev.h"
+#include "pcr_sort.h"
 
 constexpr int KN_STACK = 192;
 constexpr unsigned int KN_SCAN_T = 128;
@@ -495,14 +496,14 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
         unsigned int *d_vals = nullptr, *d_order = nullptr;
         void* d_tmp = nullptr;
         size_t tmp_bytes = 0;
-        PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_order, (size_t)q, 0, 63, ctx->stream));
+        PCR_HIP(ctx, pcr_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_order, (size_t)q, 63u, ctx->stream));
         if ((rc = pcr_dev_alloc(ctx, sizeof(int) * q, (void**)&d_redo)) || (rc = pcr_dev_alloc(ctx, 8 * (size_t)q, (void**)&d_keys)) ||
             (rc = pcr_dev_alloc(ctx, 8 * (size_t)q, (void**)&d_keys2)) || (rc = pcr_dev_alloc(ctx, 4 * (size_t)q, (void**)&d_vals)) ||
             (rc = pcr_dev_alloc(ctx, 4 * (size_t)q, (void**)&d_order)) || (rc = pcr_dev_alloc(ctx, tmp_bytes, &d_tmp)))
             return rc;
         PCR_HIP(ctx, hipMemsetAsync(d_redo_count, 0, sizeof(unsigned int), ctx->stream));
         hipLaunchKernelGGL(knn_keys_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, d_keys, d_vals);
-        PCR_HIP(ctx, rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_order, (size_t)q, 0, 63, ctx->stream));
+        PCR_HIP(ctx, pcr_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_order, (size_t)q, 63u, ctx->stream));
         const unsigned gb = (unsigned)((q + 255) / 256);
         if (k <= 8)
             hipLaunchKernelGGL(knn_tile_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (const unsigned int*)d_order, (long long)q, k,

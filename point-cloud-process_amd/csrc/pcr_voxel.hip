@@ -18,6 +18,7 @@
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "pcr_internal.h"
+#include "pcr_sort.h"
 
 // NumPy npy_divmod floor-division for doubles
 static double npy_floor_divide(double a, double b) {
@@ -37,9 +38,13 @@ static double npy_floor_divide(double a, double b) {
     return floordiv;
 }
 
+// KEY = 0: the key is the integer value of h (h is a non-negative integer below 2^52 there: exact, and only its low bits need
+// sorting), in 32 bits when they fit; KEY = 1: the bit pattern of h, which orders any non-negative binary64 exactly as the
+// reference's float64 argsort does (huge grids: a tiny leaf on a large extent takes h beyond 2^53, even 2^64).
+template <typename K, int KEY>
 __global__ void voxel_keys_kernel(const pcr_pt* __restrict__ pts, long long n, double mnx, double mny, double mnz, double leaf,
                                   double Dx, double Dy, double* __restrict__ h_out /* by row id, may be null */,
-                                  unsigned long long* __restrict__ key_bits, unsigned int* __restrict__ vals) {
+                                  K* __restrict__ key_bits, unsigned int* __restrict__ vals) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const pcr_pt p = pts[i];
@@ -50,13 +55,14 @@ __global__ void voxel_keys_kernel(const pcr_pt* __restrict__ pts, long long n, d
     if (h_out) h_out[p.id] = h;
     if (key_bits) {
         // records may be device-reordered: sort position = row id, so that ties keep INPUT order
-        key_bits[p.id] = (unsigned long long)h;  // h is a non-negative integer below 2^53: exact, and only its low bits need sorting
+        key_bits[p.id] = KEY == 0 ? (K)(unsigned long long)h : (K)(unsigned long long)__double_as_longlong(h);
         vals[p.id] = (unsigned int)i;
     }
 }
 
+template <typename K>
 struct head_flag {  // position i starts a group of equal keys
-    const unsigned long long* keys;
+    const K* keys;
     __host__ __device__ bool operator()(unsigned int i) const { return i == 0u || keys[i] != keys[i - 1u]; }
 };
 
@@ -64,53 +70,50 @@ struct head_flag {  // position i starts a group of equal keys
 // record is gathered once (not once per axis) and the 8 records of an unrolled step are requested together, so a dense
 // voxel costs n/8 dependent memory round trips instead of 3n.  Per axis the additions and their order are exactly
 // NumPy's (8 accumulators over blocks of <= 128, then the pairwise tree), so the centroids stay bitwise equal.
+struct vox_xyz { double x, y, z; };   // voxel-major copy of the coordinates (written by voxel_gather_kernel)
 struct coord_view {
-    const pcr_pt* pts;
-    const unsigned int* perm;
-    unsigned int start;
-    __device__ pcr_pt at(unsigned int k) const { return pts[perm[start + k]]; }
+    const vox_xyz* xyz;   // first record of the voxel's run
+    __device__ vox_xyz at(unsigned int k) const { return xyz[k]; }
 };
 
 struct sum3 { double x, y, z; };
 
-__device__ static sum3 pw_leaf(const coord_view& a, unsigned int off, unsigned int n) {
+// NumPy's pairwise_sum leaf (n <= 128) by the EIGHT lanes that share a voxel: lane j runs accumulator r[j] of NumPy's unrolled
+// loop (a[j] + a[8 + j] + a[16 + j] + ..., in that order), the accumulators meet in NumPy's tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+// by a three-step butterfly (IEEE addition commutes, so every lane gets the same bits), the n % 8 leftovers are added in order.
+// Same additions in the same order as one thread doing it alone -- the centroids stay bitwise NumPy's -- in an eighth of the
+// dependent steps, with coalesced 192-byte reads.
+__device__ static sum3 pw_leaf8(const coord_view& a, unsigned int off, unsigned int n, int lane8) {
+    sum3 res = {0.0, 0.0, 0.0};
     if (n < 8) {
-        sum3 res = {0.0, 0.0, 0.0};
         for (unsigned int i = 0; i < n; ++i) {
-            const pcr_pt p = a.at(off + i);
+            const vox_xyz p = a.at(off + i);
             res.x += p.x; res.y += p.y; res.z += p.z;
         }
         return res;
     }
-    double rx[8], ry[8], rz[8];
-    {
-        pcr_pt p[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) p[j] = a.at(off + j);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { rx[j] = p[j].x; ry[j] = p[j].y; rz[j] = p[j].z; }
-    }
+    vox_xyz r = a.at(off + lane8);
     unsigned int i = 8;
     for (; i < n - (n % 8); i += 8) {
-        pcr_pt p[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) p[j] = a.at(off + i + j);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { rx[j] += p[j].x; ry[j] += p[j].y; rz[j] += p[j].z; }
+        const vox_xyz p = a.at(off + i + lane8);
+        r.x += p.x; r.y += p.y; r.z += p.z;
     }
-    sum3 res;
-    res.x = ((rx[0] + rx[1]) + (rx[2] + rx[3])) + ((rx[4] + rx[5]) + (rx[6] + rx[7]));
-    res.y = ((ry[0] + ry[1]) + (ry[2] + ry[3])) + ((ry[4] + ry[5]) + (ry[6] + ry[7]));
-    res.z = ((rz[0] + rz[1]) + (rz[2] + rz[3])) + ((rz[4] + rz[5]) + (rz[6] + rz[7]));
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const double ox = __shfl_xor(r.x, d, 8), oy = __shfl_xor(r.y, d, 8), oz = __shfl_xor(r.z, d, 8);
+        r.x += ox; r.y += oy; r.z += oz;
+    }
+    res.x = r.x; res.y = r.y; res.z = r.z;
     for (; i < n; ++i) {
-        const pcr_pt p = a.at(off + i);
+        const vox_xyz p = a.at(off + i);
         res.x += p.x; res.y += p.y; res.z += p.z;
     }
     return res;
 }
 
-__device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int n) {
-    if (n <= 128) return pw_leaf(a, 0, n);
+// (off, n) and the control flow below are the same in the eight lanes of a voxel
+__device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int n, int lane8) {
+    if (n <= 128) return pw_leaf8(a, 0, n, lane8);
     // explicit stack for: sum(off, n) = n <= 128 ? leaf : sum(off, n2) + sum(off + n2, n - n2), n2 = (n/2) rounded down to 8
     struct frame { unsigned int off, n; int state; sum3 left; };
     frame st[40];
@@ -120,7 +123,7 @@ __device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int n) {
     while (sp > 0) {
         frame& f = st[sp - 1];
         if (f.n <= 128) {
-            ret = pw_leaf(a, f.off, f.n);
+            ret = pw_leaf8(a, f.off, f.n, lane8);
             --sp;
             continue;
         }
@@ -148,13 +151,27 @@ __device__ static inline unsigned long long splitmix64(unsigned long long x) {
     return x ^ (x >> 31);
 }
 
-// one thread per emitted voxel v in [0, n_groups - 1): the last group is never emitted (modes 0, 1); mode 2 emits all
-__global__ void voxel_emit_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restrict__ perm, const unsigned int* __restrict__ heads,
-                                  const unsigned int* __restrict__ n_groups_p, long long n, int mode, unsigned long long seed,
-                                  pcr_pt* __restrict__ out_pts, double* __restrict__ out_xyz) {
+// Coordinates into voxel-major order, one thread per POINT: the random 32-byte reads through the permutation happen here, a
+// million of them in flight at once; the emit kernel then streams every voxel's run.  (One thread per voxel gathering its own
+// points through the permutation -- a chain of dependent scattered reads per thread -- took 132 us at 1 M points, 18 x the
+// algorithmic traffic.)
+__global__ void __launch_bounds__(256)
+voxel_gather_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restrict__ perm, long long n, vox_xyz* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const pcr_pt p = pts[perm[i]];
+    out[i] = vox_xyz{p.x, p.y, p.z};
+}
+
+// EIGHT LANES per emitted voxel v in [0, n_groups - 1): the last group is never emitted (modes 0, 1); mode 2 emits all
+__global__ void __launch_bounds__(256)
+voxel_emit_kernel(const vox_xyz* __restrict__ xyz, const unsigned int* __restrict__ heads, const unsigned int* __restrict__ n_groups_p, long long n, int mode,
+                  unsigned long long seed, pcr_pt* __restrict__ out_pts, double* __restrict__ out_xyz) {
     const unsigned int ng = *n_groups_p;
-    const unsigned int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ng == 0 || v >= (mode == 2 ? ng : ng - 1)) return;
+    const int lane8 = threadIdx.x & 7;
+    if (ng == 0) return;
+    const unsigned int n_emit = mode == 2 ? ng : ng - 1;   // (only known on the device: a fixed grid strides over the voxels)
+    for (unsigned int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; v < n_emit; v += (gridDim.x * blockDim.x) >> 3) {
     const unsigned int s = heads[v], e = v + 1 < ng ? heads[v + 1] : (unsigned int)n;
     const unsigned int cnt = e - s;
     double ox, oy, oz;
@@ -162,19 +179,20 @@ __global__ void voxel_emit_kernel(const pcr_pt* __restrict__ pts, const unsigned
         // Open3D voxel_down_sample: running sum in input order, then one division
         ox = oy = oz = 0.0;
         for (unsigned int k = 0; k < cnt; ++k) {
-            const pcr_pt p = pts[perm[s + k]];
+            const vox_xyz p = xyz[s + k];
             ox += p.x; oy += p.y; oz += p.z;
         }
         ox /= (double)cnt; oy /= (double)cnt; oz /= (double)cnt;
     } else if (mode == 0) {
-        const coord_view a{pts, perm, s};
-        const sum3 t = numpy_pairwise_sum(a, cnt);
+        const coord_view a{xyz + s};
+        const sum3 t = numpy_pairwise_sum(a, cnt, lane8);
         ox = t.x / (double)cnt; oy = t.y / (double)cnt; oz = t.z / (double)cnt;
     } else {
         const unsigned int k = (unsigned int)(splitmix64(seed ^ ((unsigned long long)v * 0xD1B54A32D192ED03ull)) % cnt);
-        const pcr_pt p = pts[perm[s + k]];
+        const vox_xyz p = xyz[s + k];
         ox = p.x; oy = p.y; oz = p.z;
     }
+    if (lane8 != 0) continue;
     if (out_pts) {
         pcr_pt o;
         o.x = ox; o.y = oy; o.z = oz;
@@ -186,23 +204,72 @@ __global__ void voxel_emit_kernel(const pcr_pt* __restrict__ pts, const unsigned
         out_xyz[3 * (size_t)v + 1] = oy;
         out_xyz[3 * (size_t)v + 2] = oz;
     }
+    }
 }
 
 struct voxel_work {
     double mn[3], mx[3], D[3];
-    unsigned int* perm = nullptr;   // sorted position -> device record index
+    vox_xyz* xyz = nullptr;         // coordinates in voxel-major order
     unsigned int* heads = nullptr;  // group start positions
     unsigned int* n_groups = nullptr;
     int64_t n = 0;
 };
 
-// keys + sort + heads on a device cloud.  h_out_dev (by row id) optional.
+// sort of (key, row) + group heads + voxel-major coordinates for key type K
+template <typename K, int KEY>
+static int voxel_groups(pcr_ctx* ctx, const pcr_cloud* c, double leaf, int end_bit, voxel_work* w) {
+    const long long n = c->n;
+    const int grid_n = (int)((n + 255) / 256);
+    int rc;
+    K *d_keys = nullptr, *d_keys2 = nullptr;
+    unsigned int *d_vals = nullptr, *d_perm = nullptr;
+    void *d_temp = nullptr, *d_temp2 = nullptr;
+    size_t temp_bytes = 0, temp2 = 0;
+    auto release = [&]() {
+        if (d_temp) pcr_dev_free(ctx, d_temp, temp_bytes);
+        if (d_temp2) pcr_dev_free(ctx, d_temp2, temp2);
+        if (d_keys) pcr_dev_free(ctx, d_keys, sizeof(K) * n);
+        if (d_keys2) pcr_dev_free(ctx, d_keys2, sizeof(K) * n);
+        if (d_vals) pcr_dev_free(ctx, d_vals, sizeof(unsigned int) * n);
+        if (d_perm) pcr_dev_free(ctx, d_perm, sizeof(unsigned int) * n);
+    };
+    if ((rc = pcr_dev_alloc(ctx, sizeof(K) * n, (void**)&d_keys)) || (rc = pcr_dev_alloc(ctx, sizeof(K) * n, (void**)&d_keys2)) ||
+        (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals)) || (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_perm)) ||
+        (rc = pcr_dev_alloc(ctx, sizeof(vox_xyz) * n, (void**)&w->xyz)) || (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (n + 1), (void**)&w->heads))) {
+        release();
+        return rc;
+    }
+    hipLaunchKernelGGL((voxel_keys_kernel<K, KEY>), dim3(grid_n), dim3(256), 0, ctx->stream, (const pcr_pt*)c->d, n, w->mn[0], w->mn[1], w->mn[2], leaf, w->D[0],
+                       w->D[1], (double*)nullptr, d_keys, d_vals);
+    hipError_t e = pcr_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_perm, (size_t)n, (unsigned int)end_bit, ctx->stream);
+    if (e == hipSuccess) rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp);
+    if (e == hipSuccess && rc == PCR_OK) e = pcr_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_perm, (size_t)n, (unsigned int)end_bit, ctx->stream);
+    if (e == hipSuccess && rc == PCR_OK) {
+        hipLaunchKernelGGL(voxel_gather_kernel, dim3(grid_n), dim3(256), 0, ctx->stream, (const pcr_pt*)c->d, (const unsigned int*)d_perm, n, w->xyz);
+        // group heads = positions whose key differs from the previous one: one fused flag + scan + scatter (rocprim::select
+        // over a counting iterator with a computed flag), instead of a flag kernel, a scan and a scatter
+        w->n_groups = ctx->d_counters + 48;
+        const head_flag<K> flag_op{d_keys2};
+        auto positions = rocprim::counting_iterator<unsigned int>(0u);
+        auto flags = rocprim::make_transform_iterator(positions, flag_op);
+        e = rocprim::select(nullptr, temp2, positions, flags, w->heads, w->n_groups, (size_t)n, ctx->stream);
+        if (e == hipSuccess) rc = pcr_dev_alloc(ctx, temp2, &d_temp2);
+        if (e == hipSuccess && rc == PCR_OK) e = rocprim::select(d_temp2, temp2, positions, flags, w->heads, w->n_groups, (size_t)n, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    release();   // (stream-ordered with the launches above)
+    if (rc) return rc;
+    if (e != hipSuccess) { ctx->last_error = std::string("voxel filter: ") + hipGetErrorString(e); return PCR_E_HIP; }
+    return PCR_OK;
+}
+
+// keys (+ sort + heads + voxel-major coordinates when need_groups) on a device cloud.  h_out_dev (by row id) optional.
 static int voxel_prepare(pcr_ctx* ctx, const pcr_cloud* c, double leaf, double* h_out_dev, bool need_groups, voxel_work* w,
                          bool open3d_binning = false) {
     if (!(leaf > 0) || !std::isfinite(leaf)) return PCR_E_INVALID;
     const long long n = c->n;
     w->n = n;
-    int rc = pcr_bbox(ctx, c->d, n, w->mn, w->mx);
+    int rc = pcr_cloud_bbox(ctx, c, w->mn, w->mx);   // (the box remembered from the upload when there is one: no reduction, no read-back)
     if (rc) return rc;
     if (open3d_binning) {
         // Open3D: voxel_min_bound = min - voxel_size/2, index = floor((p - voxel_min_bound) / voxel_size); every cell distinct
@@ -213,67 +280,35 @@ static int voxel_prepare(pcr_ctx* ctx, const pcr_cloud* c, double leaf, double* 
         if (w->D[0] * w->D[1] * w->D[2] >= 9007199254740992.0) { ctx->last_error = "voxel_size is too small"; return PCR_E_INVALID; }
     } else
     for (int k = 0; k < 3; ++k) w->D[k] = npy_floor_divide(w->mx[k] - w->mn[k], leaf);
-    const int block = 256;
-    const int grid_n = (int)((n + block - 1) / block);
-    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
-    unsigned int* d_vals = nullptr;
-    if (need_groups) {
-        if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys))) return rc;
-        if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * n, (void**)&d_keys2))) return rc;
-        if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals))) return rc;
-        if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&w->perm))) return rc;
+    if (!need_groups) {
+        hipLaunchKernelGGL((voxel_keys_kernel<unsigned long long, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const pcr_pt*)c->d, n, w->mn[0],
+                           w->mn[1], w->mn[2], leaf, w->D[0], w->D[1], h_out_dev, (unsigned long long*)nullptr, (unsigned int*)nullptr);
+        PCR_HIP(ctx, hipGetLastError());
+        return PCR_OK;
     }
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3(grid_n), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, n, w->mn[0], w->mn[1], w->mn[2],
-                       leaf, w->D[0], w->D[1], h_out_dev, d_keys, d_vals);
-    PCR_HIP(ctx, hipGetLastError());
-    if (!need_groups) return PCR_OK;
     // keys are non-negative integers bounded by the grid: sort only the bits they can occupy (a KITTI scan at 0.2 m needs
-    // 25 of the 64: half the radix passes)
-    int end_bit = 63;
-    {
-        double bound = 0.0;
-        if (open3d_binning) {
-            bound = w->D[0] * w->D[1] * w->D[2];
-        } else {
-            const double Hx = floor((w->mx[0] - w->mn[0]) / leaf), Hy = floor((w->mx[1] - w->mn[1]) / leaf), Hz = floor((w->mx[2] - w->mn[2]) / leaf);
-            bound = (Hx + Hy * w->D[0]) + (Hz * w->D[0]) * w->D[1];
-        }
-        if (bound >= 0.0 && bound < 4503599627370496.0) {  // 2^52
-            unsigned long long b = (unsigned long long)bound + 1ull;
-            end_bit = 1;
-            while ((b >> end_bit) != 0ull) ++end_bit;
-        }
+    // 25 of the 64: 32-bit keys, half the radix passes).  A grid so fine that h may leave the exactly representable integers
+    // (bound >= 2^52) is sorted by the bit pattern of h, all 64 bits, like the reference's float64 argsort.
+    double bound = 0.0;
+    if (open3d_binning) {
+        bound = w->D[0] * w->D[1] * w->D[2];
+    } else {
+        const double Hx = floor((w->mx[0] - w->mn[0]) / leaf), Hy = floor((w->mx[1] - w->mn[1]) / leaf), Hz = floor((w->mx[2] - w->mn[2]) / leaf);
+        bound = (Hx + Hy * w->D[0]) + (Hz * w->D[0]) * w->D[1];
     }
-    size_t temp_bytes = 0;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, w->perm, (size_t)n, 0, end_bit, ctx->stream));
-    void* d_temp = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp))) return rc;
-    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, w->perm, (size_t)n, 0, end_bit, ctx->stream));
-    if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (n + 1), (void**)&w->heads))) return rc;
-    w->n_groups = ctx->d_counters + 48;
-    // group heads = positions whose key differs from the previous one: one fused flag + scan + scatter (rocprim::select
-    // over a counting iterator with a computed flag), instead of a flag kernel, a scan and a scatter
-    const head_flag flag_op{d_keys2};
-    auto positions = rocprim::counting_iterator<unsigned int>(0u);
-    auto flags = rocprim::make_transform_iterator(positions, flag_op);
-    size_t temp2 = 0;
-    PCR_HIP(ctx, rocprim::select(nullptr, temp2, positions, flags, w->heads, w->n_groups, (size_t)n, ctx->stream));
-    void* d_temp2 = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, temp2, &d_temp2))) return rc;
-    PCR_HIP(ctx, rocprim::select(d_temp2, temp2, positions, flags, w->heads, w->n_groups, (size_t)n, ctx->stream));
-    PCR_HIP(ctx, hipGetLastError());
-    pcr_dev_free(ctx, d_temp, temp_bytes);
-    pcr_dev_free(ctx, d_temp2, temp2);
-    pcr_dev_free(ctx, d_keys, sizeof(unsigned long long) * n);
-    pcr_dev_free(ctx, d_keys2, sizeof(unsigned long long) * n);
-    pcr_dev_free(ctx, d_vals, sizeof(unsigned int) * n);
-    return PCR_OK;
+    if (!(bound >= 0.0 && bound < 4503599627370496.0)) return voxel_groups<unsigned long long, 1>(ctx, c, leaf, 64, w);   // 2^52 (also NaN / inf)
+    unsigned long long b = (unsigned long long)bound + 1ull;
+    int end_bit = 1;
+    while ((b >> end_bit) != 0ull) ++end_bit;
+    if (end_bit <= 32) return voxel_groups<unsigned int, 0>(ctx, c, leaf, end_bit, w);
+    return voxel_groups<unsigned long long, 0>(ctx, c, leaf, end_bit, w);
 }
 
 static void voxel_release(pcr_ctx* ctx, voxel_work* w) {
-    if (w->perm) pcr_dev_free(ctx, w->perm, sizeof(unsigned int) * w->n);
+    if (w->xyz) pcr_dev_free(ctx, w->xyz, sizeof(vox_xyz) * w->n);
     if (w->heads) pcr_dev_free(ctx, w->heads, sizeof(unsigned int) * (w->n + 1));
-    w->perm = w->heads = nullptr;
+    w->xyz = nullptr;
+    w->heads = nullptr;
 }
 
 extern "C" {
@@ -308,9 +343,11 @@ static int voxel_filter_impl(pcr_ctx* ctx, const pcr_cloud* in, double leaf, int
     // the number of groups is only known on the device: launch for the upper bound (threads past the last emitted voxel
     // leave at once) and read the count once everything is queued -- no host round trip in the middle of the chain
     {
-        const int block = 128;
-        hipLaunchKernelGGL(voxel_emit_kernel, dim3((unsigned)((in->n + block - 1) / block)), dim3(block), 0, ctx->stream,
-                           (const pcr_pt*)in->d, (const unsigned int*)w.perm, (const unsigned int*)w.heads, (const unsigned int*)w.n_groups,
+        const int block = 256;   // 32 voxels per block (8 lanes each)
+        long long blocks = (in->n * 8 + block - 1) / block;
+        if (blocks > 16ll * ctx->cu_count) blocks = 16ll * ctx->cu_count;
+        hipLaunchKernelGGL(voxel_emit_kernel, dim3((unsigned)blocks), dim3(block), 0, ctx->stream,
+                           (const vox_xyz*)w.xyz, (const unsigned int*)w.heads, (const unsigned int*)w.n_groups,
                            (long long)in->n, mode, (unsigned long long)seed, out_pts, out_xyz_dev);
         PCR_HIP(ctx, hipGetLastError());
     }

@@ -105,6 +105,25 @@ def test_voxel_filter_fuzz_bit_exact(pcp, oracle, case):
         assert out.shape == ref.shape and np.array_equal(out, ref)
 
 
+def test_voxel_filter_huge_grid_keys_beyond_2_53(pcp, oracle):
+    """A tiny leaf on a large extent: h = hx + hy*Dx + hz*Dx*Dy leaves the exactly representable integers (> 2^53, here even
+    > 2^64).  The reference sorts the float64 h itself (voxel_filter.py:36); the device then sorts the BIT PATTERN of h
+    (monotone for h >= 0) instead of its integer value -- groups, order and centroids stay those of the restatement."""
+    rng = np.random.default_rng(77)
+    base = rng.uniform(0.0, 200.0, (1500, 3))
+    pts = np.concatenate([base, base[:400] + rng.uniform(0, 1e-6, (400, 3))])    # some voxels hold two points
+    rng.shuffle(pts)
+    leaf = 5e-5
+    h, D = pcp.voxel_keys(pts, leaf)
+    oh, oD = oracle.voxel_keys(pts, leaf)
+    assert np.array_equal(D, oD) and np.array_equal(h, oh)
+    assert oh.max() > 2.0 ** 64
+    out = pcp.voxel_filter(pts, leaf, "centroid")
+    ref = oracle.voxel_filter(pts, leaf, "centroid")[0]
+    assert out.shape == ref.shape and np.array_equal(out, ref)
+    assert len(ref) < len(pts) - 1          # (really some shared voxels)
+
+
 KNN = [("uniform", 3000, 1), ("uniform", 3000, 8), ("uniform", 40, 64), ("clusters", 20000, 5), ("plane", 20000, 17), ("lattice", 4000, 9), ("line", 5000, 3)]
 
 
