@@ -333,15 +333,7 @@ unsigned int next_pow2_host(unsigned long long v) {
     return (unsigned int)p;
 }
 
-struct dev_block {
-    pcr_ctx* ctx;
-    void* p = nullptr;
-    size_t bytes = 0;
-    explicit dev_block(pcr_ctx* c) : ctx(c) {}
-    int alloc(size_t b) { bytes = b; return pcr_dev_alloc(ctx, b, &p); }
-    ~dev_block() { if (p) pcr_dev_free(ctx, p, bytes); }
-    template <typename T> T* as() const { return (T*)p; }
-};
+using dev_block = pcr_dev_block;
 
 // the per-pair path (what pcr_icp_batch did for every pair before the fused stages; still used for what they cannot take)
 int run_one_pair(pcr_ctx* ctx, const pcr_pair& P, const pcr_icp_params* params, pcr_icp_result* res) {

@@ -139,6 +139,19 @@ PCR_HIDDEN int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out);
 PCR_HIDDEN void pcr_dev_free(pcr_ctx* ctx, void* p, size_t bytes);
 // records of a cloud in caller row order (the device copy may be Morton-reordered)
 PCR_HIDDEN int pcr_cloud_rows(pcr_ctx* ctx, const pcr_cloud* c, pcr_pt* d_out);
+
+// device scratch that goes back to the context's arena when it leaves scope (every return path, error or not)
+struct pcr_dev_block {
+    pcr_ctx* ctx;
+    void* p = nullptr;
+    size_t bytes = 0;
+    explicit pcr_dev_block(pcr_ctx* c) : ctx(c) {}
+    pcr_dev_block(const pcr_dev_block&) = delete;
+    pcr_dev_block& operator=(const pcr_dev_block&) = delete;
+    int alloc(size_t b) { bytes = b; return pcr_dev_alloc(ctx, b, &p); }
+    ~pcr_dev_block() { if (p) pcr_dev_free(ctx, p, bytes); }
+    template <typename T> T* as() const { return (T*)p; }
+};
 constexpr int PCR_MAX_LANES = 4;
 constexpr int PCR_SLABS_PER_LANE = 256;
 // d_counters: words 0..1023 small per-subsystem counters; from word 1024 on, 1024 words per search lane for the

@@ -209,10 +209,14 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
                 ids[j] = cand[--heap_n];
             }
             std::vector<pcr_pt> recs(batch);
-            PCR_HIP(ctx, hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(iss_gather_kernel, dim3(1), dim3((unsigned)BATCH), 0, ctx->stream, (const pcr_pt*)d_rows, (const int*)d_ids, (int)batch, d_batch);
-            PCR_HIP(ctx, hipMemcpyAsync(recs.data(), d_batch, sizeof(pcr_pt) * batch, hipMemcpyDeviceToHost, ctx->stream));
-            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            // (errors leave through the clean-up below: the scratch blocks and the index go back on every path)
+            hipError_t e = hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(iss_gather_kernel, dim3(1), dim3((unsigned)BATCH), 0, ctx->stream, (const pcr_pt*)d_rows, (const int*)d_ids, (int)batch, d_batch);
+                e = hipMemcpyAsync(recs.data(), d_batch, sizeof(pcr_pt) * batch, hipMemcpyDeviceToHost, ctx->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("pcr_iss (suppression): ") + hipGetErrorString(e); rc = PCR_E_HIP; break; }
             bool done = false;
             for (size_t j = 0; j < batch && !done; ++j) {
                 const pcr_pt& c = recs[j];

@@ -479,63 +479,54 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
     if (q <= 0) return PCR_OK;
     if (index->kind != PCR_INDEX_GRID) return PCR_E_UNSUPPORTED;
     hipSetDevice(ctx->device);
-    double* d_q = nullptr;
-    int* d_idx = nullptr;
-    double* d_dist = nullptr;
+    pcr_dev_block b_q(ctx), b_idx(ctx), b_dist(ctx), b_redo(ctx), b_keys(ctx), b_keys2(ctx), b_vals(ctx), b_order(ctx), b_tmp(ctx);
     int rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 3 * q, (void**)&d_q))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(int) * q * k, (void**)&d_idx))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * q * k, (void**)&d_dist))) return rc;
-    PCR_HIP(ctx, hipMemcpyAsync(d_q, queries, sizeof(double) * 3 * q, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = b_q.alloc(sizeof(double) * 3 * q)) || (rc = b_idx.alloc(sizeof(int) * q * k)) || (rc = b_dist.alloc(sizeof(double) * q * k))) return rc;
+    const double* d_q = b_q.as<const double>();
+    int* d_idx = b_idx.as<int>();
+    double* d_dist = b_dist.as<double>();
+    PCR_HIP(ctx, hipMemcpyAsync(b_q.p, queries, sizeof(double) * 3 * q, hipMemcpyHostToDevice, ctx->stream));
     static const bool no_block = getenv("PCR_KNN_NO_BLOCK") != nullptr;
     if (k <= 16 && q >= 256 && !no_block) {
         // batched path: queries along the index's Morton curve, wave tiles, then the wave-per-query descent for what they could not prove
-        int* d_redo = nullptr;
         unsigned int* d_redo_count = ctx->d_counters + 125;
-        unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
-        unsigned int *d_vals = nullptr, *d_order = nullptr;
-        void* d_tmp = nullptr;
+        unsigned long long *kn = nullptr;
+        unsigned int* vn = nullptr;
         size_t tmp_bytes = 0;
-        PCR_HIP(ctx, pcr_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_order, (size_t)q, 63u, ctx->stream));
-        if ((rc = pcr_dev_alloc(ctx, sizeof(int) * q, (void**)&d_redo)) || (rc = pcr_dev_alloc(ctx, 8 * (size_t)q, (void**)&d_keys)) ||
-            (rc = pcr_dev_alloc(ctx, 8 * (size_t)q, (void**)&d_keys2)) || (rc = pcr_dev_alloc(ctx, 4 * (size_t)q, (void**)&d_vals)) ||
-            (rc = pcr_dev_alloc(ctx, 4 * (size_t)q, (void**)&d_order)) || (rc = pcr_dev_alloc(ctx, tmp_bytes, &d_tmp)))
+        PCR_HIP(ctx, pcr_sort_pairs(nullptr, tmp_bytes, kn, kn, vn, vn, (size_t)q, 63u, ctx->stream));
+        if ((rc = b_redo.alloc(sizeof(int) * q)) || (rc = b_keys.alloc(8 * (size_t)q)) || (rc = b_keys2.alloc(8 * (size_t)q)) || (rc = b_vals.alloc(4 * (size_t)q)) ||
+            (rc = b_order.alloc(4 * (size_t)q)) || (rc = b_tmp.alloc(tmp_bytes)))
             return rc;
+        int* d_redo = b_redo.as<int>();
+        unsigned int* d_order = b_order.as<unsigned int>();
         PCR_HIP(ctx, hipMemsetAsync(d_redo_count, 0, sizeof(unsigned int), ctx->stream));
-        hipLaunchKernelGGL(knn_keys_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, d_keys, d_vals);
-        PCR_HIP(ctx, pcr_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_order, (size_t)q, 63u, ctx->stream));
+        hipLaunchKernelGGL(knn_keys_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, b_keys.as<unsigned long long>(),
+                           b_vals.as<unsigned int>());
+        PCR_HIP(ctx, pcr_sort_pairs(b_tmp.p, tmp_bytes, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(), b_vals.as<unsigned int>(), d_order, (size_t)q, 63u,
+                                    ctx->stream));
         const unsigned gb = (unsigned)((q + 255) / 256);
         if (k <= 8)
-            hipLaunchKernelGGL(knn_tile_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (const unsigned int*)d_order, (long long)q, k,
-                               d_idx, d_dist, d_redo, d_redo_count);
+            hipLaunchKernelGGL(knn_tile_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (const unsigned int*)d_order, (long long)q, k, d_idx, d_dist,
+                               d_redo, d_redo_count);
         else
-            hipLaunchKernelGGL(knn_tile_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (const unsigned int*)d_order, (long long)q, k,
-                               d_idx, d_dist, d_redo, d_redo_count);
+            hipLaunchKernelGGL(knn_tile_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (const unsigned int*)d_order, (long long)q, k, d_idx, d_dist,
+                               d_redo, d_redo_count);
         unsigned int n_redo = 0;
         PCR_HIP(ctx, hipMemcpyAsync(&n_redo, d_redo_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         static const bool dbg = getenv("PCR_KNN_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "pcr_knn: %lld queries, k = %d: %u to the wave-per-query descent\n", (long long)q, k, n_redo);
         if (n_redo)
-            hipLaunchKernelGGL(knn_kernel, dim3((n_redo + 3) / 4), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, k, d_idx,
-                               d_dist, (const int*)d_redo, (const unsigned int*)d_redo_count);
-        pcr_dev_free(ctx, d_redo, sizeof(int) * q);
-        pcr_dev_free(ctx, d_keys, 8 * (size_t)q);
-        pcr_dev_free(ctx, d_keys2, 8 * (size_t)q);
-        pcr_dev_free(ctx, d_vals, 4 * (size_t)q);
-        pcr_dev_free(ctx, d_order, 4 * (size_t)q);
-        pcr_dev_free(ctx, d_tmp, tmp_bytes);
+            hipLaunchKernelGGL(knn_kernel, dim3((n_redo + 3) / 4), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, (const int*)d_redo,
+                               (const unsigned int*)d_redo_count);
     } else {
-        hipLaunchKernelGGL(knn_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, k,
-                           d_idx, d_dist, (const int*)nullptr, (const unsigned int*)nullptr);
+        hipLaunchKernelGGL(knn_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, (const int*)nullptr,
+                           (const unsigned int*)nullptr);
     }
     PCR_HIP(ctx, hipGetLastError());
     if ((rc = pcr_d2h_staged(ctx, idx_out, d_idx, sizeof(int) * (size_t)q * k))) return rc;
     if ((rc = pcr_d2h_staged(ctx, dist_out, d_dist, sizeof(double) * (size_t)q * k))) return rc;
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pcr_dev_free(ctx, d_q, sizeof(double) * 3 * q);
-    pcr_dev_free(ctx, d_idx, sizeof(int) * q * k);
-    pcr_dev_free(ctx, d_dist, sizeof(double) * q * k);
     return PCR_OK;
 }
 
@@ -547,64 +538,50 @@ int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries, int6
     if (q <= 0) return PCR_OK;
     if (index->kind != PCR_INDEX_GRID) return PCR_E_UNSUPPORTED;
     hipSetDevice(ctx->device);
-    double* d_q = nullptr;
-    long long* d_counts = nullptr;
-    long long* d_offs = nullptr;
-    int* d_idx = nullptr;
-    double* d_dist = nullptr;
+    // (every scratch block goes back to the arena on every return path)
+    pcr_dev_block d_q(ctx), d_counts(ctx), d_offs(ctx), d_idx(ctx), d_dist(ctx), d_idx2(ctx), d_dist2(ctx), d_tmp(ctx);
     int rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 3 * q, (void**)&d_q))) return rc;
-    PCR_HIP(ctx, hipMemcpyAsync(d_q, queries, sizeof(double) * 3 * q, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = d_q.alloc(sizeof(double) * 3 * q))) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(d_q.p, queries, sizeof(double) * 3 * q, hipMemcpyHostToDevice, ctx->stream));
     const unsigned grid = (unsigned)((q + 3) / 4);
     if (!offsets) {
-        if ((rc = pcr_dev_alloc(ctx, sizeof(long long) * q, (void**)&d_counts))) return rc;
-        hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, radius,
-                           d_counts, (const long long*)nullptr, (int*)nullptr, (double*)nullptr);
+        if ((rc = d_counts.alloc(sizeof(long long) * q))) return rc;
+        hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, d_q.as<const double>(), (long long)q, radius,
+                           d_counts.as<long long>(), (const long long*)nullptr, (int*)nullptr, (double*)nullptr);
         PCR_HIP(ctx, hipGetLastError());
-        PCR_HIP(ctx, hipMemcpyAsync(counts_out, d_counts, sizeof(long long) * q, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, hipMemcpyAsync(counts_out, d_counts.p, sizeof(long long) * q, hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        pcr_dev_free(ctx, d_counts, sizeof(long long) * q);
-    } else {
-        const int64_t total = offsets[q];
-        if ((rc = pcr_dev_alloc(ctx, sizeof(long long) * (q + 1), (void**)&d_offs))) return rc;
-        if ((rc = pcr_dev_alloc(ctx, sizeof(int) * (total + 1), (void**)&d_idx))) return rc;
-        if ((rc = pcr_dev_alloc(ctx, sizeof(double) * (total + 1), (void**)&d_dist))) return rc;
-        PCR_HIP(ctx, hipMemcpyAsync(d_offs, offsets, sizeof(long long) * (q + 1), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)q, radius,
-                           (long long*)nullptr, (const long long*)d_offs, d_idx, d_dist);
-        PCR_HIP(ctx, hipGetLastError());
-        // Ascending distance (ties by index) inside every query's segment, on the device: two stable segmented radix sorts (by
-        // index, then by distance).  The host used to sort the 15.7 M neighbours of 20 000 queries on 16 threads after a pageable
-        // 190-MB copy; now the lists arrive ordered, through a pinned double buffer.
-        if (total > 0) {
-            int* d_idx2 = nullptr;
-            double* d_dist2 = nullptr;
-            if ((rc = pcr_dev_alloc(ctx, sizeof(int) * (total + 1), (void**)&d_idx2))) return rc;
-            if ((rc = pcr_dev_alloc(ctx, sizeof(double) * (total + 1), (void**)&d_dist2))) return rc;
-            size_t tb1 = 0, tb2 = 0;
-            PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tb1, d_idx, d_idx2, d_dist, d_dist2, (unsigned int)total, (unsigned int)q, d_offs, d_offs + 1, 0,
-                                                             32, ctx->stream));
-            PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tb2, d_dist2, d_dist, d_idx2, d_idx, (unsigned int)total, (unsigned int)q, d_offs, d_offs + 1, 0,
-                                                             64, ctx->stream));
-            const size_t tb = tb1 > tb2 ? tb1 : tb2;
-            void* d_tmp = nullptr;
-            if ((rc = pcr_dev_alloc(ctx, tb > 0 ? tb : 16, &d_tmp))) return rc;
-            PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(d_tmp, tb1, d_idx, d_idx2, d_dist, d_dist2, (unsigned int)total, (unsigned int)q, d_offs, d_offs + 1, 0, 32,
-                                                             ctx->stream));
-            PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(d_tmp, tb2, d_dist2, d_dist, d_idx2, d_idx, (unsigned int)total, (unsigned int)q, d_offs, d_offs + 1, 0, 64,
-                                                             ctx->stream));
-            if ((rc = pcr_d2h_staged(ctx, idx_out, d_idx, sizeof(int) * (size_t)total))) return rc;
-            if ((rc = pcr_d2h_staged(ctx, dist_out, d_dist, sizeof(double) * (size_t)total))) return rc;
-            pcr_dev_free(ctx, d_tmp, tb > 0 ? tb : 16);
-            pcr_dev_free(ctx, d_idx2, sizeof(int) * (total + 1));
-            pcr_dev_free(ctx, d_dist2, sizeof(double) * (total + 1));
-        }
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        pcr_dev_free(ctx, d_offs, sizeof(long long) * (q + 1));
-        pcr_dev_free(ctx, d_idx, sizeof(int) * (total + 1));
-        pcr_dev_free(ctx, d_dist, sizeof(double) * (total + 1));
+        return PCR_OK;
     }
-    pcr_dev_free(ctx, d_q, sizeof(double) * 3 * q);
+    const int64_t total = offsets[q];
+    if (total < 0) return PCR_E_INVALID;
+    // the segmented sorts below index with 32 bits: more than 2^32 - 1 neighbours in one call (it fits in 288 GB) is refused
+    // rather than silently truncated
+    if (total > 0xffffffffll) { ctx->last_error = "pcr_radius: more than 2^32 - 1 neighbours in one call; split the queries"; return PCR_E_UNSUPPORTED; }
+    if ((rc = d_offs.alloc(sizeof(long long) * (q + 1))) || (rc = d_idx.alloc(sizeof(int) * (total + 1))) || (rc = d_dist.alloc(sizeof(double) * (total + 1)))) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(d_offs.p, offsets, sizeof(long long) * (q + 1), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, d_q.as<const double>(), (long long)q, radius,
+                       (long long*)nullptr, d_offs.as<const long long>(), d_idx.as<int>(), d_dist.as<double>());
+    PCR_HIP(ctx, hipGetLastError());
+    // Ascending distance (ties by index) inside every query's segment, on the device: two stable segmented radix sorts (by
+    // index, then by distance).  The host used to sort the 15.7 M neighbours of 20 000 queries on 16 threads after a pageable
+    // 190-MB copy; now the lists arrive ordered, through a pinned double buffer.
+    if (total > 0) {
+        if ((rc = d_idx2.alloc(sizeof(int) * (total + 1))) || (rc = d_dist2.alloc(sizeof(double) * (total + 1)))) return rc;
+        int *i1 = d_idx.as<int>(), *i2 = d_idx2.as<int>();
+        double *x1 = d_dist.as<double>(), *x2 = d_dist2.as<double>();
+        long long* offs = d_offs.as<long long>();
+        size_t tb1 = 0, tb2 = 0;
+        PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tb1, i1, i2, x1, x2, (unsigned int)total, (unsigned int)q, offs, offs + 1, 0, 32, ctx->stream));
+        PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tb2, x2, x1, i2, i1, (unsigned int)total, (unsigned int)q, offs, offs + 1, 0, 64, ctx->stream));
+        const size_t tb = tb1 > tb2 ? tb1 : tb2;
+        if ((rc = d_tmp.alloc(tb > 0 ? tb : 16))) return rc;
+        PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(d_tmp.p, tb1, i1, i2, x1, x2, (unsigned int)total, (unsigned int)q, offs, offs + 1, 0, 32, ctx->stream));
+        PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(d_tmp.p, tb2, x2, x1, i2, i1, (unsigned int)total, (unsigned int)q, offs, offs + 1, 0, 64, ctx->stream));
+        if ((rc = pcr_d2h_staged(ctx, idx_out, i1, sizeof(int) * (size_t)total))) return rc;
+        if ((rc = pcr_d2h_staged(ctx, dist_out, x1, sizeof(double) * (size_t)total))) return rc;
+    }
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCR_OK;
 }
 
