@@ -198,7 +198,10 @@ PCR_API int pcr_voxel_filter_cloud(pcr_ctx* ctx, const pcr_cloud* in, double lea
 /* --------------------------------------------------------------------- ISS
  * Keypoint_detection_ISS/ISS.py:35-73.  lambdas_out (n,3) descending eigenvalues
  * of the weighted scatter; counts_out[n] = |N(p_i)| (inclusive radius, self
- * included).  keypoints_out holds up to max_keypoints indices after NMS.     */
+ * included).  keypoints_out holds up to max_keypoints + 1 indices after NMS
+ * (ISS.py:72-73 stops once MORE than iss_count were taken).  lambdas_out and
+ * counts_out may be NULL (they are 28 bytes per point over PCIe); at least
+ * one of lambdas_out / keypoints_out must be asked for.                       */
 PCR_API int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, double gamma21, double gamma32, double nms_radius,
                     int max_keypoints, double* lambdas_out, int32_t* counts_out, int32_t* keypoints_out, int* n_keypoints_out);
 

@@ -63,6 +63,8 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
     if (hipHostMalloc(&c->h_state, 8192, hipHostMallocDefault) != hipSuccess) { delete c; return PCR_E_NOMEM; }
     if (hipMalloc((void**)&c->d_counters, PCR_COUNTER_BYTES) != hipSuccess) { delete c; return PCR_E_NOMEM; }
     hipMemsetAsync(c->d_counters, 0, PCR_COUNTER_BYTES, c->stream);
+    if (hipMalloc((void**)&c->d_cell_counts, 4 * (PCR_MAX_LEVELS * 64 + 64)) != hipSuccess) { delete c; return PCR_E_NOMEM; }
+    hipMemsetAsync(c->d_cell_counts, 0, 4 * (PCR_MAX_LEVELS * 64 + 64), c->stream);
     if (getenv("PCR_DEBUG_STAMPS")) {
         hipMalloc((void**)&c->d_debug, sizeof(unsigned long long) << 20);
         hipMemsetAsync(c->d_debug, 0, sizeof(unsigned long long) << 20, c->stream);
@@ -87,6 +89,7 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     for (void* a : c->arenas) hipFree(a);
     if (c->d_partials) hipFree(c->d_partials);
     if (c->d_counters) hipFree(c->d_counters);
+    if (c->d_cell_counts) hipFree(c->d_cell_counts);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_slabs) hipHostFree(c->h_slabs);
     if (c->h_state) hipHostFree(c->h_state);

@@ -115,6 +115,7 @@ struct pcr_ctx {
     double* d_partials = nullptr;
     size_t d_partials_bytes = 0;
     unsigned int* d_counters = nullptr;  // small zeroed scratch (tickets, flags)
+    unsigned int* d_cell_counts = nullptr;  // [PCR_MAX_LEVELS][64] + ticket: run-start counters of the index build, zero between builds
     unsigned long long* d_debug = nullptr;  // diagnostics stamps (PCR_DEBUG_STAMPS=1), 1 Mi words
     // optional per-kernel profile of the ICP pass
     bool profile = false;

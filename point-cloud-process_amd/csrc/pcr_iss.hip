@@ -8,10 +8,14 @@
 // 3x3x3 block of its cell.  Two passes, 8 lanes per point, lane-owned cells:
 //   pass 1  |N(p_i)|            (16 B point + 4 B count per point: HBM-trivial, cache-resident gathers)
 //   pass 2  weighted scatter + symmetric 3x3 eigenvalues (Jacobi, binary64) -> 3 doubles per point
-// The NMS is a short sequential host loop over radius queries (<= max_keypoints + 1 of them).
+// (Wave tiles -- 64 consecutive points of the sorted cloud staging the cells of their common box into LDS once, the way the
+// batched k-NN does -- were built and measured here: 0.94 + 1.89 ms at 1 M points, k = 38, against 0.55 + 1.17 ms: both
+// passes are bound by the binary64 distance evaluations, and a common box holds 1.5-2 x the candidates of a point's own 27
+// cells.)  The NMS is a short sequential host loop over the candidates in lambda_3 order.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 #include "pcr_grid_dev.h"
@@ -46,16 +50,13 @@ __device__ static inline void iss_visit_block(const pcr_grid_view& gv, double ax
     }
 }
 
-__global__ void __launch_bounds__(256) iss_count_kernel(pcr_grid_view gv, long long n, double radius, int* __restrict__ counts /* by row id */) {
+__global__ void __launch_bounds__(256) iss_count_kernel(pcr_grid_view gv, long long n, double r2_in, int* __restrict__ counts /* by row id */) {
     const int gl = threadIdx.x % IG;
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / IG;
     if (i >= n) return;
     const pcr_pt p = gv.pts[i];
     int c = 0;
-    auto f = [&](const pcr_pt& b) {
-        const double d = sqrt(dist2(p.x, p.y, p.z, b));
-        c += !(d > radius);
-    };
+    auto f = [&](const pcr_pt& b) { c += dist2(p.x, p.y, p.z, b) <= r2_in; };
     iss_visit_block(gv, p.x, p.y, p.z, gl, f);
 #pragma unroll
     for (int off = IG / 2; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
@@ -93,7 +94,7 @@ __device__ static inline void sym3_eigenvalues(double a00, double a01, double a0
     ev[0] = e0; ev[1] = e1; ev[2] = e2;
 }
 
-__global__ void __launch_bounds__(256) iss_cov_kernel(pcr_grid_view gv, long long n, double radius, const int* __restrict__ counts,
+__global__ void __launch_bounds__(256) iss_cov_kernel(pcr_grid_view gv, long long n, double r2_in, const int* __restrict__ counts,
                                                       double* __restrict__ lambdas /* by row id, (n,3) */, double gamma21, double gamma32,
                                                       int* __restrict__ cand /* row ids passing the ratio tests, any order */,
                                                       unsigned int* __restrict__ cand_count) {
@@ -104,8 +105,7 @@ __global__ void __launch_bounds__(256) iss_cov_kernel(pcr_grid_view gv, long lon
     double m[7] = {0, 0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz, denom
     auto f = [&](const pcr_pt& b) {
         const double dx = b.x - p.x, dy = b.y - p.y, dz = b.z - p.z;
-        const double d = sqrt((dx * dx + dy * dy) + dz * dz);
-        if (!(d > radius)) {
+        if ((dx * dx + dy * dy) + dz * dz <= r2_in) {
             const double w = 1.0 / (double)counts[b.id];
             m[0] += w * (dx * dx); m[1] += w * (dx * dy); m[2] += w * (dx * dz);
             m[3] += w * (dy * dy); m[4] += w * (dy * dz); m[5] += w * (dz * dz);
@@ -133,6 +133,12 @@ __global__ void __launch_bounds__(256) iss_cov_kernel(pcr_grid_view gv, long lon
     }
 }
 
+
+__global__ void iss_cand_l3_kernel(const double* __restrict__ lam, const int* __restrict__ cand, unsigned int m, double* __restrict__ out) {
+    const unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) out[j] = lam[3 * (size_t)cand[j] + 2];
+}
+
 __global__ void iss_gather_kernel(const pcr_pt* __restrict__ rows, const int* __restrict__ ids, int m, pcr_pt* __restrict__ out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < m) out[j] = rows[ids[j]];
@@ -140,7 +146,8 @@ __global__ void iss_gather_kernel(const pcr_pt* __restrict__ rows, const int* __
 
 extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, double gamma21, double gamma32, double nms_radius,
                        int max_keypoints, double* lambdas_out, int32_t* counts_out, int32_t* keypoints_out, int* n_keypoints_out) {
-    if (!ctx || !cloud || !lambdas_out || !(radius > 0)) return PCR_E_INVALID;
+    if (!ctx || !cloud || !(radius > 0)) return PCR_E_INVALID;
+    if (!lambdas_out && !(keypoints_out && n_keypoints_out)) return PCR_E_INVALID;   // nothing asked for
     if (cloud->n <= 0) return PCR_E_EMPTY;
     hipSetDevice(ctx->device);
     const int64_t n = cloud->n;
@@ -161,33 +168,56 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
         if ((rc = pcr_dev_alloc(ctx, sizeof(int) * n, (void**)&d_cand))) return rc;
         PCR_HIP(ctx, hipMemsetAsync(d_cand_count, 0, sizeof(unsigned int), ctx->stream));
     }
-    hipLaunchKernelGGL(iss_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, radius, d_counts);
-    hipLaunchKernelGGL(iss_cov_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, radius, (const int*)d_counts, d_lam, gamma21,
+    // "within radius" is `not (sqrt(d2) > radius)` (the radius query's expression, pcr_knn.hip).  sqrt is monotone and correctly
+    // rounded, so that is `d2 <= r2_in` with r2_in the LARGEST binary64 whose square root does not exceed the radius: same
+    // decisions bit for bit, no square root per candidate (it was most of the VALU work of both passes).
+    double r2_in = radius * radius;
+    while (sqrt(r2_in) > radius) r2_in = nextafter(r2_in, 0.0);
+    while (sqrt(nextafter(r2_in, INFINITY)) <= radius) r2_in = nextafter(r2_in, INFINITY);
+    hipLaunchKernelGGL(iss_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, r2_in, d_counts);
+    hipLaunchKernelGGL(iss_cov_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, r2_in, (const int*)d_counts, d_lam, gamma21,
                        gamma32, d_cand, d_cand_count);
     PCR_HIP(ctx, hipGetLastError());
-    // (24 MB + 4 MB at 1 M points: through the pinned double buffer, a pageable copy runs at ~4.5 GB/s)
-    if ((rc = pcr_d2h_staged(ctx, lambdas_out, d_lam, sizeof(double) * 3 * (size_t)n))) return rc;
+    // (24 MB + 4 MB at 1 M points: through the pinned double buffer, a pageable copy runs at ~4.5 GB/s.  Both are optional: a
+    // caller that only wants the keypoints gets the candidates' lambda_3 in a compact list instead -- the copy was most of the
+    // call's wall time)
+    if (lambdas_out && (rc = pcr_d2h_staged(ctx, lambdas_out, d_lam, sizeof(double) * 3 * (size_t)n))) return rc;
     if (counts_out && (rc = pcr_d2h_staged(ctx, counts_out, d_counts, sizeof(int) * (size_t)n))) return rc;
     unsigned int n_cand = 0;
     if (want_kp) PCR_HIP(ctx, hipMemcpyAsync(&n_cand, d_cand_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pcr_dev_free(ctx, d_counts, sizeof(int) * n);
-    pcr_dev_free(ctx, d_lam, sizeof(double) * 3 * n);
     rc = PCR_OK;
+    std::vector<double> cand_l3(n_cand);
+    if (want_kp && n_cand) {   // lambda_3 of the candidates, in list order
+        double* d_l3 = nullptr;
+        if ((rc = pcr_dev_alloc(ctx, sizeof(double) * n_cand, (void**)&d_l3)) == PCR_OK) {
+            hipLaunchKernelGGL(iss_cand_l3_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, ctx->stream, (const double*)d_lam, (const int*)d_cand, n_cand, d_l3);
+            hipError_t e = hipMemcpyAsync(cand_l3.data(), d_l3, sizeof(double) * n_cand, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("pcr_iss: ") + hipGetErrorString(e); rc = PCR_E_HIP; }
+            pcr_dev_free(ctx, d_l3, sizeof(double) * n_cand);
+        }
+    }
+    pcr_dev_free(ctx, d_lam, sizeof(double) * 3 * n);
+    if (rc) { if (d_cand) pcr_dev_free(ctx, d_cand, sizeof(int) * n); pcr_index_free(ctx, idx); return rc; }
     if (want_kp) {
         // Non-maximum suppression (ISS.py:59-73).  The reference walks the candidates in descending lambda_3 (stable: ties
         // in input order) and, for each one still alive, keeps it and removes everything within nms_radius of it.  A
         // candidate is therefore dropped exactly when an ALREADY KEPT keypoint lies within nms_radius: at most
         // max_keypoints + 1 distance checks per candidate on the host, no radius queries; and only the head of the order is
         // ever visited, so the candidates sit in a heap instead of being sorted.
-        std::vector<int> cand(n_cand);
+        struct cand_t { int id; double l3; };
+        std::vector<cand_t> cand(n_cand);
         if (n_cand) {
-            PCR_HIP(ctx, hipMemcpyAsync(cand.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, ctx->stream));
-            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            std::vector<int> ids(n_cand);
+            hipError_t e = hipMemcpyAsync(ids.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("pcr_iss: ") + hipGetErrorString(e); rc = PCR_E_HIP; }
+            for (unsigned int j = 0; j < n_cand; ++j) cand[j] = cand_t{ids[j], cand_l3[j]};
         }
-        auto later = [&](int a, int b) {  // heap order: a comes AFTER b
-            const double la = lambdas_out[3 * (size_t)a + 2], lb = lambdas_out[3 * (size_t)b + 2];
-            return la < lb || (la == lb && a > b);
+        auto later = [&](const cand_t& a, const cand_t& b) {  // heap order: a comes AFTER b
+            return a.l3 < b.l3 || (a.l3 == b.l3 && a.id > b.id);
         };
         std::make_heap(cand.begin(), cand.end(), later);
         // coordinates of the visited candidates only: fetched in small batches by row id
@@ -206,7 +236,7 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
             std::vector<int> ids(batch);
             for (size_t j = 0; j < batch; ++j) {
                 std::pop_heap(cand.begin(), cand.begin() + heap_n, later);
-                ids[j] = cand[--heap_n];
+                ids[j] = cand[--heap_n].id;
             }
             std::vector<pcr_pt> recs(batch);
             // (errors leave through the clean-up below: the scratch blocks and the index go back on every path)

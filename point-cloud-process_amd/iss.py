@@ -20,12 +20,14 @@ def iss_keypoints(points, radius=0.5, lambda21=0.5, lambda32=0.5, non_max_radius
     if not isinstance(points, DeviceCloud):
         cloud = own = DeviceCloud.upload(points_of(points), ctx)
     n = cloud.n
-    lam = np.empty((n, 3), dtype=np.float64)
-    counts = np.empty(n, dtype=np.int32)
+    # the per-point eigenvalues and neighbour counts (24 + 4 bytes per point over PCIe: most of the call at 1 M points) are only
+    # read back when asked for; the keypoints need the candidates' lambda_3 only, which the library fetches as a compact list
+    lam = np.empty((n, 3), dtype=np.float64) if return_details else None
+    counts = np.empty(n, dtype=np.int32) if return_details else None
     kp = np.empty(int(iss_count) + 1, dtype=np.int32)
     nk = C.c_int()
     L.check(L.lib().pcr_iss(ctx.handle, cloud.handle, float(radius), float(lambda21), float(lambda32), float(non_max_radius), int(iss_count),
-                            L.dptr(lam), L.iptr(counts), L.iptr(kp), C.byref(nk)), ctx.handle)
+                            L.dptr(lam) if return_details else None, L.iptr(counts) if return_details else None, L.iptr(kp), C.byref(nk)), ctx.handle)
     if own is not None:
         own.free()
     idx = [int(i) for i in kp[: nk.value]]
