@@ -217,7 +217,7 @@ int pcr_normals(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double* normals_out
     // cell such that a sphere of one cell radius holds ~2k points of a surface-like cloud (n points over
     // the two largest extents of the bounding box): then the 3x3x3 block answers almost every point.
     double lo[3], hi[3];
-    int rc = pcr_bbox(ctx, cloud->d, n, lo, hi);
+    int rc = pcr_cloud_bbox(ctx, cloud, lo, hi);
     if (rc) return rc;
     double e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
     if (e[0] < e[1]) std::swap(e[0], e[1]);
