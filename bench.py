@@ -54,6 +54,16 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2    # wave64 VALU instructions per second: 
 BATCH_PAIRS, BATCH_POINTS = 256, 20_000
 
 
+def profile_file(name):
+    """Newest committed rocprofv3 counter summary of that name under profiles/ (r03_..., else r02_...): counters cannot be
+    collected inside this process, so the per-launch HBM traffic and instruction counts come from the committed passes."""
+    for tag in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", f"{tag}_{name}")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r03_" + name)
+
+
 def launch_ranks(n):
     """Start n ranks of this script under torch.distributed.run and relay their output.  Runs BEFORE this process makes
     any GPU call (a process that has initialised the GPU must never be replaced or re-exec'd)."""
@@ -539,13 +549,13 @@ def main():
             algo_bytes = GRID_BYTES_PER_CORR * n_src
             traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                pmc = json.load(open(profile_file("pmc_traffic.json")))
                 traffic = pmc["kernels"][dom].get("hbm_bytes") if a.points == N_POINTS else None
             except Exception:
                 traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": algo_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / dom_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_source": "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc passes of the same command), not measured in this run",
+                        "traffic_source": os.path.relpath(profile_file("pmc_traffic.json"), ROOT) + " (separate rocprofv3 --pmc passes of the same command), not measured in this run",
                         "note": "working set (2 x 3.8 MB) is L2/MALL resident; this kernel is VALU-issue and latency bound, not HBM bound: see roofline_valu"}
         else:
             flops = 8.0 * n_src * a.points
@@ -580,7 +590,7 @@ def main():
             # what actually bounds the pass: VALU issue.  Wave instructions per launch from the committed SQ counter passes (rocprofv3
             # cannot run inside this process), over this run's kernel duration, against one wave64 VALU instruction per SIMD every 2 cycles.
             try:
-                sqc = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")))["kernels"]["grid_pass_kernel"]
+                sqc = json.load(open(profile_file("sq_counters.json")))["kernels"]["grid_pass_kernel"]
                 n_valu = sqc["SQ_INSTS_VALU"] if a.points == N_POINTS else None
                 fpairs, mean_p = filter_pairs_per_pass(pkg, dev_id, src, tgt, a.cell)
                 pass_s = kern["grid_pass_kernel"] * 1e-6
@@ -588,7 +598,7 @@ def main():
                                          "achieved": None if n_valu is None else n_valu / pass_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9,
                                          "unit": "G wave-instructions/s", "frac": None if n_valu is None else n_valu / pass_s / VALU_ISSUE_PEAK,
                                          "valu_instructions_per_launch": n_valu,
-                                         "source": "profiles/r02_sq_counters.json (SQ_INSTS_VALU, separate rocprofv3 --pmc pass of the same pair)",
+                                         "source": os.path.relpath(profile_file("sq_counters.json"), ROOT) + " (SQ_INSTS_VALU, separate rocprofv3 --pmc pass of the same pair)",
                                          "filter_pairs_per_launch": fpairs, "mean_candidates_per_query": mean_p,
                                          "note": "whole launch incl. the tail in which most waves wait for the slowest tiles; during the tile stage "
                                                  "(first ~12 us) the SIMDs issue VALU back to back (DESIGN.md 3.1); the filter itself runs on the "

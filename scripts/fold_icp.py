@@ -1,7 +1,8 @@
-"""Fold scripts/profile_icp.sh's rocprofv3 outputs into the files committed under profiles/ (r02_*)."""
+"""Fold scripts/profile_icp.sh's rocprofv3 outputs into the files committed under profiles/ (<TAG>_*, TAG from the environment, default r03)."""
 import collections, csv, glob, json, os, shutil, sys
 
 out = sys.argv[1]
+TAG = os.environ.get("TAG", "r03")
 
 
 def counters(sub):
@@ -14,9 +15,9 @@ def counters(sub):
 
 for name in ("grid", "brute", "bench"):
     for f in glob.glob(os.path.join(out, name + "_stats", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(out, f"r02_{name}_kernel_stats.csv"))
+        shutil.copy(f, os.path.join(out, f"{TAG}_{name}_kernel_stats.csv"))
 traffic = {"note": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum), `python3 scripts/prof_pass.py "
-                   "grid 10` (ten ICP passes of the 120k x 120k pair inside the device-resident loop), mean per launch, final code of round 2; "
+                   "grid 10` (ten ICP passes of the 120k x 120k pair inside the device-resident loop), mean per launch; "
                    "FETCH_SIZE / WRITE_SIZE in KiB as reported; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md "
                    "(gfx950 halves FETCH_SIZE on 16-B/lane reads; uncalibrated for this kernel's scattered 16..64-byte accesses; "
                    "Infinity-Cache hits are counted)", "kernels": {}}
@@ -29,12 +30,12 @@ for k in f:
     if e["TCC_HIT_sum"] and e["TCC_MISS_sum"] is not None:
         e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
     traffic["kernels"][k] = e
-json.dump(traffic, open(os.path.join(out, "r02_pmc_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(out, TAG + "_pmc_traffic.json"), "w"), indent=1)
 sq = {}
 for sub in ("sq1", "sq2", "sq3"):
     for k, d in counters(sub).items():
         sq.setdefault(k, {}).update(d)
-with open(os.path.join(out, "r02_sq_counters.txt"), "w") as fh:
+with open(os.path.join(out, TAG + "_sq_counters.txt"), "w") as fh:
     fh.write("rocprofv3 --pmc (three passes) -- python3 scripts/prof_pass.py grid 10   (MI355X, 120k x 120k pair, mean per launch, whole chip;\n"
              "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_INSTS_* count wave instructions)\n\n")
     names = sorted({c for d in sq.values() for c in d})
@@ -50,11 +51,11 @@ with open(os.path.join(out, "r02_sq_counters.txt"), "w") as fh:
                                                                         4 * d["SQ_WAVE_CYCLES"] / d["SQ_WAVES"], 100 * d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"],
                                                                         100 * d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_WAVE_CYCLES"]))
 json.dump({"note": "rocprofv3 --pmc (three passes) -- python3 scripts/prof_pass.py grid 10; mean per launch, whole chip", "kernels": sq},
-          open(os.path.join(out, "r02_sq_counters.json"), "w"), indent=1)
-print(open(os.path.join(out, "r02_sq_counters.txt")).read())
+          open(os.path.join(out, TAG + "_sq_counters.json"), "w"), indent=1)
+print(open(os.path.join(out, TAG + "_sq_counters.txt")).read())
 print(json.dumps(traffic["kernels"], indent=1))
 for name in ("grid", "brute", "bench"):
-    p = os.path.join(out, f"r02_{name}_kernel_stats.csv")
+    p = os.path.join(out, f"{TAG}_{name}_kernel_stats.csv")
     if os.path.exists(p):
         print(name, "kernel stats:")
         for row in list(csv.DictReader(open(p)))[:6]:

@@ -5,7 +5,7 @@
 
 Prints one JSON line: wall ms per call (device-resident inputs where the API allows) + the algorithmic bytes
 SURVEY 8d assigns to the op.  scripts/profile_other.sh runs it under rocprofv3 (--kernel-trace --stats, then
-FETCH_SIZE / WRITE_SIZE in separate passes) and folds everything into profiles/r02_other_configs.json."""
+FETCH_SIZE / WRITE_SIZE in separate passes) and folds everything into profiles/r03_other_configs.json."""
 import importlib, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel stats + HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate passes as MI355X_MICROARCH.md prescribes)
 # for the kernels outside the ICP pass.  Output: gpurun_out/other/<op>/..., folded into gpurun_out/other/summary.json
-# (copy to profiles/r02_other_configs.json).
+# (copy to profiles/r03_other_configs.json).
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
