@@ -521,7 +521,7 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     {
         unsigned long long* kn = nullptr;
         unsigned int* vn = nullptr;
-        if (pcr_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, (size_t)slots, (unsigned int)(mbits + cbits), ctx->stream) != hipSuccess) return PCR_E_HIP;
+        if (rocprim::radix_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, (size_t)slots, 0, (unsigned int)(mbits + cbits), ctx->stream) != hipSuccess) return PCR_E_HIP;
     }
     // small things in one block: clouds | targets | T0s | counts | cell offsets | plan | pairs | running
     const size_t s_cl = 0, s_tg = off_tg - off_cl, s_T0 = off_T0 - off_cl, s_in_end = off_st - off_cl;   // (same layout as the pinned block)
@@ -556,8 +556,10 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     if (use_dma) PCR_HIP(ctx, hipMemcpyAsync(d_in.p, h_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(batch_keys_kernel, dim3(blocks_all), dim3(SLOT), 0, st, use_dma ? d_in.as<float>() : (const float*)hp_dev, d_in.as<float>(), d_cl, n_clouds,
                        mbits, d_keys.as<unsigned long long>(), d_vals.as<unsigned int>());
-    PCR_HIP(ctx, pcr_sort_pairs(d_tmp.p, temp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned int>(),
-                                d_vals2.as<unsigned int>(), (size_t)slots, (unsigned int)(mbits + cbits), st));
+    // (rocPRIM's default configuration = merge sort at this size.  Onesweep is faster for one sort of 1.3 M pairs alone -- 126 against
+    // 190 us -- but not with eight sub-batches' sorts in flight together, and it adds a dozen 17-us fills per sort.)
+    PCR_HIP(ctx, rocprim::radix_sort_pairs(d_tmp.p, temp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned int>(),
+                                           d_vals2.as<unsigned int>(), (size_t)slots, 0, (unsigned int)(mbits + cbits), st));
     hipLaunchKernelGGL(batch_gather_kernel, dim3(blocks_all), dim3(SLOT), 0, st, d_in.as<float>(), d_vals2.as<unsigned int>(), d_cl, n_clouds, d_pts.as<pcr_pt>());
     // ---- grids of all targets
     if (blocks_tgt)

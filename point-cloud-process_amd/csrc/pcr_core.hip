@@ -388,13 +388,14 @@ expand_cloud_kernel(const S* __restrict__ in, long long n, long long stride, pcr
         if ((threadIdx.x & 63) == 0) atomicMax(&s_box[a], k[a]);
     }
     __syncthreads();
-    if (threadIdx.x < 6) atomicMax(&box[threadIdx.x], s_box[threadIdx.x]);
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&box[6], 1ull) == (unsigned long long)gridDim.x - 1ull ? 1 : 0;   // ticket
+    // (no fence: device-scope atomics are performed at the coherence point, and an agent-scope release is an L2 write-back on
+    // this chip -- with __threadfence() here the kernel took 82 us instead of 30 at 120 000 points.  The six maxima are
+    // acknowledged (vmcnt) before the same wave takes the ticket.)
+    if (threadIdx.x < 6) __hip_atomic_fetch_max(&box[threadIdx.x], s_box[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&box[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1ull ? 1 : 0;   // ticket
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (threadIdx.x < 7) {
         const unsigned long long w = __hip_atomic_load(&box[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x < 6) host_box[threadIdx.x] = w;

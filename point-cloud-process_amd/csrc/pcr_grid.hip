@@ -95,13 +95,14 @@ gather_count_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restri
     __syncthreads();
     // 64 counters per level (block & 63): a million points are 3 900 blocks, and atomics on ONE word are served at ~90 per
     // microsecond (0.41 ms of 0.78 for a 1 M-point index with one counter per level)
-    if ((int)threadIdx.x < levels && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x * 64 + (blockIdx.x & 63u)], s_cnt[threadIdx.x]);
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&counts[PCR_MAX_LEVELS * 64], 1u) == gridDim.x - 1 ? 1 : 0;   // ticket
+    // (no fence: device-scope atomics are performed at the coherence point -- an agent-scope release is an L2 write-back on this
+    // chip; the adds are acknowledged (vmcnt) before the same wave takes the ticket)
+    if ((int)threadIdx.x < levels && s_cnt[threadIdx.x])
+        __hip_atomic_fetch_add(&counts[threadIdx.x * 64 + (blockIdx.x & 63u)], s_cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&counts[PCR_MAX_LEVELS * 64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;   // ticket
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     for (int l = threadIdx.x >> 6; l < PCR_MAX_LEVELS; l += 4) {   // wave w sums levels w, w + 4, w + 8
         unsigned int v = __hip_atomic_load(&counts[l * 64 + (threadIdx.x & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         counts[l * 64 + (threadIdx.x & 63)] = 0;

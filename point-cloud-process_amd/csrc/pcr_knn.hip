@@ -19,7 +19,6 @@
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "pcr_grid_dev.h"
-#include "pcr_sort.h"
 
 constexpr int KN_STACK = 192;
 constexpr unsigned int KN_SCAN_T = 128;
@@ -227,244 +226,111 @@ radius_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq
 
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Batched k-NN (k <= 16), wave tiles: the queries are ordered along the index's Morton curve, ONE WAVE takes 64 consecutive
-// ones (a lane each) and stages the cells of their common box -- the cells of all 64 queries, one ring around them -- into
-// its LDS slice ONCE; every lane then scans the staged points (broadcast LDS reads, no divergence) keeping its k best in
-// registers (constant-index insertion, ties by index: the order of a stable sort of all distances).  A query is proven when
-// its k-th distance is inside the ball the staged box certainly covers; the others go one level up (cells 4 x larger), and
-// what the levels cannot prove (clamped coordinates, very sparse surroundings, k > points nearby) to the wave-per-query
-// descent.  One lane per query walking its own 27 cells in global memory (round 2) was bound by dependent scattered loads:
-// 1.81 ms for 120 000 queries, k = 8; a tile reads every cell once for 64 queries.
-constexpr int KT_PTS = 384;         // points staged per round
-constexpr int KT_LIST = 512;        // occupied cells of a tile's box
-constexpr int KT_BOX = 2048;        // cells of a tile's box (occupied or not)
-constexpr int KT_ROUNDS = 8;        // rounds per pass a group of 4 lanes may take before its queries are handed to the descent
-constexpr int KT_PASSES = 3;
-constexpr int KT_ROUNDS_SPLIT = 3;  // ... and a larger group before it is split into quarters
-
-struct knn_tile_lds {
-    double x[KT_PTS], y[KT_PTS], z[KT_PTS];
-    int id[KT_PTS];
-    unsigned int c_start[KT_LIST], c_pre[KT_LIST + 1];
-};
-
-// LDS hand-off between the lanes of one wave (LDS operations of a wave execute in order; the compiler must not move them)
-__device__ static inline void kt_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ static inline int kt_wave_min(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-    return v;
-}
-__device__ static inline int kt_wave_max(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
-}
-
-__global__ void __launch_bounds__(256)
-knn_keys_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq, unsigned long long* __restrict__ keys, unsigned int* __restrict__ vals) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    bool cl = false;
-    const unsigned long long cx = (unsigned long long)cell_coord(queries[3 * i], gv.lo[0], gv.inv_cell0, &cl);
-    const unsigned long long cy = (unsigned long long)cell_coord(queries[3 * i + 1], gv.lo[1], gv.inv_cell0, &cl);
-    const unsigned long long cz = (unsigned long long)cell_coord(queries[3 * i + 2], gv.lo[2], gv.inv_cell0, &cl);
-    keys[i] = spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2);
-    vals[i] = (unsigned int)i;
-}
-
+// (Wave tiles for this batch -- queries along the Morton curve, 64 per wave, the cells of their common box staged into LDS once,
+// a ball-driven second pass, adaptive lane groups -- were built and measured this round against the kernel below on the same
+// box: 120 000 x 120 000, k = 8: 6.5 ms against 3.0; the cloud against itself 1.50 against 1.19; normals 2.6 against 1.8.  A
+// common box holds 3-5 x the candidates of a query's own 27 cells, every staged point costs every lane ~100 cycles of binary64
+// distance + list insertion, and one wave serving 64 queries of very different needs is the kernel's tail.)
+// Batched k-NN, first stage (k <= 16): ONE LANE per query scans the 3x3x3 block of cells around it and keeps the k best
+// (d2, index) pairs in registers, sorted.  The block covers every point within the distance from the query to the
+// block's nearest face (>= one cell), so the result is exact when the k-th distance does not exceed that; level 0 is
+// tried first, then level 1 (cells 4x wider), then -- in sparse surroundings only -- levels 2 and 3.  Queries it cannot prove (sparse surroundings, fewer than k points in
+// reach, coordinates outside the grid) go to a list for the wave-per-query descent above.  On a KITTI scan the block
+// scan settles > 95 % of the queries at ~1/40 of the descent's cost per query.
+#ifndef PCR_KNN_LV
+#define PCR_KNN_LV 3
+#endif
 template <int K>
 __global__ void __launch_bounds__(256)
-knn_tile_kernel(pcr_grid_view gv, const double* __restrict__ queries, const unsigned int* __restrict__ order, long long nq, int k, int* __restrict__ idx_out,
-                double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count) {
-    __shared__ knn_tile_lds s_lds[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    knn_tile_lds* L = &s_lds[wave];
-    const long long slot = ((long long)blockIdx.x * 4 + wave) * 64 + lane;
-    const bool valid = slot < nq;
-    const long long qi = valid ? (long long)order[slot] : 0;
-    double ax = 0, ay = 0, az = 0;
-    bool clamped = false;
-    int c0[3] = {0, 0, 0};
-    if (valid) {
-        ax = queries[3 * qi]; ay = queries[3 * qi + 1]; az = queries[3 * qi + 2];
-        c0[0] = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
-        c0[1] = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
-        c0[2] = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
-    }
-    bool open = valid && !clamped;     // still to be proven
+knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq, int k, int* __restrict__ idx_out,
+                 double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count) {
+    const long long qi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     bool proven = false;
     double bd[K];
     long long bi[K];
+    if (qi < nq) {
+        const double ax = queries[3 * qi], ay = queries[3 * qi + 1], az = queries[3 * qi + 2];
+        bool clamped = false;
+        const int cx = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
+        const int cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
+        const int cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
+        // levels 0, 1 and -- only where the surroundings are sparse (few points met one level down) -- 2 and 3
+        const int max_level = gv.levels - 1 < PCR_KNN_LV ? gv.levels - 1 : PCR_KNN_LV;
+        unsigned int met = 0;
+        for (int level = 0; level <= max_level && !clamped && !proven && (level < 2 || met <= 192u); ++level) {
+            met = 0;
 #pragma unroll
-    for (int j = 0; j < K; ++j) { bd[j] = DBL_MAX; bi[j] = 0x7fffffffffffffffll; }
-    const int top = gv.levels - 1;
-    // Pass 0 stages the queries' own level-0 cells and one ring.  A query that found k points there knows a ball that holds its
-    // answer (radius = its k-th distance so far): the next pass stages the box of those balls -- in cells of the finest level
-    // that keeps the box small -- and proves it.  A query with fewer than k points asks for 4, then 16 cells around itself.
-    for (int pass = 0; pass < KT_PASSES; ++pass) {
-        if (!__ballot(open)) break;
-        int lo0[3], hi0[3];   // this lane's box in level-0 cell coordinates
-        {
-            double kth = DBL_MAX;
+            for (int j = 0; j < K; ++j) { bd[j] = DBL_MAX; bi[j] = 0x7fffffffffffffffll; }
+            const int X0 = cx >> (2 * level), Y0 = cy >> (2 * level), Z0 = cz >> (2 * level);
+            const int lim = (int)(PCR_COORD_MAX >> (2 * level));
+            for (int c3 = 0; c3 < 9; ++c3) {
+              const int Y = Y0 + (c3 % 3) - 1, Z = Z0 + (c3 / 3) - 1;
+              if (Y < 0 || Z < 0 || Y > lim || Z > lim) continue;
+              unsigned int s3[3] = {0, 0, 0}, e3[3] = {0, 0, 0};
+              const unsigned int found = lookup_cell3(gv.table[level], gv.mask[level], (unsigned int)X0, (unsigned int)Y, (unsigned int)Z, (unsigned int)lim, s3, e3);
 #pragma unroll
-            for (int j = 0; j < K; ++j) kth = (j == k - 1) ? bd[j] : kth;
-            const double a[3] = {ax, ay, az};
-            if (pass > 0 && kth < DBL_MAX) {
-                const double r = sqrt(kth) * (1.0 + 1e-9) + gv.cell0 * 1e-6;
-                bool cl = false;
+              for (int cx3 = 0; cx3 < 3; ++cx3) {
+                if (!((found >> cx3) & 1u)) continue;
+                const unsigned int s = s3[cx3], e = e3[cx3];
+                met += e - s;
+                // four records per trip, requested together: one thread walking a cell record by record is a chain of dependent
+                // loads (2.2 ms for 120 000 queries, k = 8, at two waves per SIMD)
+                for (unsigned int j0 = s; j0 < e; j0 += 4) {
+                    pcr_pt rec[4];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    lo0[d] = cell_coord(a[d] - r, gv.lo[d], gv.inv_cell0, &cl);
-                    hi0[d] = cell_coord(a[d] + r, gv.lo[d], gv.inv_cell0, &cl);
-                }
-            } else {
-                const int ring = 1 << (2 * (pass < 9 ? pass : 9));
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < e) rec[u] = gv.pts[j0 + u];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) { lo0[d] = max(c0[d] - ring, 0); hi0[d] = min(c0[d] + ring, (int)PCR_COORD_MAX); }
-            }
-        }
-        // The wave works through GROUPS of its lanes: all 64 at once when their common box is small enough to stage, else the four
-        // quarters of the group one after the other (queries far apart -- a jump of the curve, a query set much sparser than
-        // the index -- share little: smaller groups, smaller boxes), down to 4 lanes; what even 4 cannot take goes to the descent (single
-        // lanes in the tile measured slower: 36 such queries of a 120 000-point scan cost the wave that owns them more than the
-        // 0.2 ms the descent takes for all of them side by side).
-        // All 64 lanes stage for every group.
-        int g_first[16], g_size[16];
-        int sp = 1;
-        g_first[0] = 0; g_size[0] = 64;
-        while (sp > 0) {
-            --sp;
-            const int gf = g_first[sp], gs = g_size[sp];
-            const bool mine = open && lane >= gf && lane < gf + gs;
-            if (!__ballot(mine)) continue;
-            int w0[3], w1[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                w0[d] = kt_wave_min(mine ? lo0[d] : 0x7fffffff);
-                w1[d] = kt_wave_max(mine ? hi0[d] : 0);
-            }
-            int level = 0;
-            long long ncell = 0;
-            for (; level <= top; ++level) {
-                ncell = (long long)((w1[0] >> (2 * level)) - (w0[0] >> (2 * level)) + 1) * ((w1[1] >> (2 * level)) - (w0[1] >> (2 * level)) + 1) *
-                        ((w1[2] >> (2 * level)) - (w0[2] >> (2 * level)) + 1);
-                if (ncell <= KT_BOX) break;
-            }
-            bool too_much = level > top;
-            if (too_much) level = top;
-            const int x0 = w0[0] >> (2 * level), y0 = w0[1] >> (2 * level), z0 = w0[2] >> (2 * level);
-            const int dx = (w1[0] >> (2 * level)) - x0 + 1, dy = (w1[1] >> (2 * level)) - y0 + 1;
-            const int b1[3] = {w1[0] >> (2 * level), w1[1] >> (2 * level), w1[2] >> (2 * level)};
-            // ---- directory: occupied cells of the box and the exclusive prefix of their point counts
-            unsigned int n_list = 0, n_pts = 0;
-            for (int base = 0; !too_much && base < (int)ncell; base += 64) {
-                const int c = base + lane;
-                unsigned int cs = 0, ce = 0;
-                bool found = false;
-                if (c < (int)ncell) {
-                    const int X = x0 + c % dx, Y = y0 + (c / dx) % dy, Z = z0 + c / (dx * dy);
-                    found = lookup_cell(gv.table[level], gv.mask[level], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &cs, &ce);
-                }
-                const unsigned long long fm = __ballot(found);
-                unsigned int cnt = found ? ce - cs : 0u, inc = cnt;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const unsigned int o = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc += o;
-                }
-                const unsigned int li = n_list + (unsigned int)__popcll(fm & ((1ull << lane) - 1ull));
-                if (found && li < KT_LIST) { L->c_start[li] = cs; L->c_pre[li] = n_pts + inc - cnt; }
-                n_list += (unsigned int)__popcll(fm);
-                n_pts += __shfl(inc, 63, 64);
-                if (n_list > KT_LIST) too_much = true;
-            }
-            too_much = too_much || n_pts > (unsigned int)((gs > 4 ? KT_ROUNDS_SPLIT : KT_ROUNDS) * KT_PTS);
-            if (too_much) {
-                if (gs > 4) {   // the quarters, first lanes on top of the stack
-                    for (int qd = 3; qd >= 0; --qd) { g_first[sp] = gf + qd * (gs / 4); g_size[sp] = gs / 4; ++sp; }
-                } else if (mine) open = false;   // descent (redo list)
-                continue;
-            }
-            if (lane == 0) L->c_pre[n_list] = n_pts;
-            if (mine) {
-#pragma unroll
-                for (int j = 0; j < K; ++j) { bd[j] = DBL_MAX; bi[j] = 0x7fffffffffffffffll; }
-            }
-            // ---- rounds: stage up to KT_PTS points, every lane of the group scans them
-            for (unsigned int r0 = 0; r0 < n_pts; r0 += KT_PTS) {
-                const unsigned int cnt = min(n_pts - r0, (unsigned int)KT_PTS);
-                kt_wave_sync();   // the directory (first round) / the last scan's reads are done
-                for (unsigned int t = lane; t < cnt; t += 64) {
-                    const unsigned int j = r0 + t;
-                    unsigned int lo = 0, hi = n_list - 1;   // last cell whose prefix <= j
-                    while (lo < hi) {
-                        const unsigned int mid = (lo + hi + 1) >> 1;
-                        if (L->c_pre[mid] <= j) lo = mid;
-                        else hi = mid - 1;
-                    }
-                    const pcr_pt rec = gv.pts[L->c_start[lo] + (j - L->c_pre[lo])];
-                    L->x[t] = rec.x; L->y[t] = rec.y; L->z[t] = rec.z; L->id[t] = (int)rec.id;
-                }
-                kt_wave_sync();
-                if (mine) {
-#pragma unroll 4
-                    for (unsigned int t = 0; t < cnt; ++t) {
-                        const double ex = ax - L->x[t], ey = ay - L->y[t], ez = az - L->z[t];
-                        double d2 = (ex * ex + ey * ey) + ez * ez;
-                        long long id = (long long)L->id[t];
+                    for (int u = 0; u < 4; ++u) {
+                        if (j0 + u >= e) break;
+                        double d2 = dist2(ax, ay, az, rec[u]);
+                        long long id = rec[u].id;
                         if (!better(d2, id, bd[K - 1], bi[K - 1])) continue;
+                        // insertion into the sorted list with constant indices: the displaced element travels down
 #pragma unroll
-                        for (int u = 0; u < K; ++u) {
-                            if (better(d2, id, bd[u], bi[u])) {
-                                const double td = bd[u]; const long long ti = bi[u];
-                                bd[u] = d2; bi[u] = id;
+                        for (int t = 0; t < K; ++t) {
+                            if (better(d2, id, bd[t], bi[t])) {
+                                const double td = bd[t]; const long long ti = bi[t];
+                                bd[t] = d2; bi[t] = id;
                                 d2 = td; id = ti;
                             }
                         }
                     }
                 }
+              }
             }
-            kt_wave_sync();
-            // ---- radius the staged box certainly covers: distance to its nearest face (beyond the grid's coordinate range there
-            // are no points; a clamped box only makes the bound smaller)
-            if (mine) {
-                const double cell = gv.cell0 * (double)(1ll << (2 * level));
-                const int bl = (int)(PCR_COORD_BIAS >> (2 * level));
-                const double a[3] = {ax, ay, az};
-                const int b0[3] = {x0, y0, z0};
-                double cover = DBL_MAX;
+            // radius the block certainly covers: distance to its nearest face
+            const double cell = gv.cell0 * (double)(1ll << (2 * level));
+            const int bl = (int)(PCR_COORD_BIAS >> (2 * level));
+            const double a[3] = {ax, ay, az};
+            const int C0[3] = {X0, Y0, Z0};
+            double cover = DBL_MAX;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const double f_lo = gv.lo[d] + (double)(b0[d] - bl) * cell, f_hi = gv.lo[d] + (double)(b1[d] + 1 - bl) * cell;
-                    cover = fmin(cover, fmin(a[d] - f_lo, f_hi - a[d]));
-                }
-                cover = fmax(cover - cell * 1e-9, 0.0);
-                double kth = DBL_MAX;
+            for (int d = 0; d < 3; ++d) {
+                const double f_lo = gv.lo[d] + (double)(C0[d] - 1 - bl) * cell, f_hi = gv.lo[d] + (double)(C0[d] + 2 - bl) * cell;
+                cover = fmin(cover, fmin(a[d] - f_lo, f_hi - a[d]));
+            }
+            cover = fmax(cover - cell * 1e-9, 0.0);
+            // the k-th neighbour (1-based k) must exist and lie inside the covered ball
+            double kth = DBL_MAX;
 #pragma unroll
-                for (int j = 0; j < K; ++j) kth = (j == k - 1) ? bd[j] : kth;
-                if (kth <= cover * cover) {
-                    proven = true;
-                    open = false;
+            for (int j = 0; j < K; ++j) kth = (j == k - 1) ? bd[j] : kth;
+            proven = kth <= cover * cover;
+        }
+        if (proven) {
 #pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        if (j < k) {
-                            idx_out[qi * k + j] = (int)bi[j];
-                            dist_out[qi * k + j] = sqrt(bd[j]);
-                        }
-                    }
+            for (int j = 0; j < K; ++j) {
+                if (j < k) {
+                    idx_out[qi * k + j] = (int)bi[j];
+                    dist_out[qi * k + j] = sqrt(bd[j]);
                 }
             }
-        }   // groups
+        }
     }
-    const bool redo = valid && !proven;
+    const bool redo = qi < nq && !proven;
     const unsigned long long m = __ballot(redo);
     if (m) {
+        const int lane = threadIdx.x & 63;
         unsigned int base = 0;
         if (lane == 0) base = atomicAdd(redo_count, (unsigned int)__popcll(m));
         base = __shfl(base, 0, 64);
@@ -479,7 +345,7 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
     if (q <= 0) return PCR_OK;
     if (index->kind != PCR_INDEX_GRID) return PCR_E_UNSUPPORTED;
     hipSetDevice(ctx->device);
-    pcr_dev_block b_q(ctx), b_idx(ctx), b_dist(ctx), b_redo(ctx), b_keys(ctx), b_keys2(ctx), b_vals(ctx), b_order(ctx), b_tmp(ctx);
+    pcr_dev_block b_q(ctx), b_idx(ctx), b_dist(ctx), b_redo(ctx);   // (back to the arena on every return path)
     int rc;
     if ((rc = b_q.alloc(sizeof(double) * 3 * q)) || (rc = b_idx.alloc(sizeof(int) * q * k)) || (rc = b_dist.alloc(sizeof(double) * q * k))) return rc;
     const double* d_q = b_q.as<const double>();
@@ -488,34 +354,19 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
     PCR_HIP(ctx, hipMemcpyAsync(b_q.p, queries, sizeof(double) * 3 * q, hipMemcpyHostToDevice, ctx->stream));
     static const bool no_block = getenv("PCR_KNN_NO_BLOCK") != nullptr;
     if (k <= 16 && q >= 256 && !no_block) {
-        // batched path: queries along the index's Morton curve, wave tiles, then the wave-per-query descent for what they could not prove
+        // batched path: lane-per-query block scan, then the wave-per-query descent for what it could not prove
         unsigned int* d_redo_count = ctx->d_counters + 125;
-        unsigned long long *kn = nullptr;
-        unsigned int* vn = nullptr;
-        size_t tmp_bytes = 0;
-        PCR_HIP(ctx, pcr_sort_pairs(nullptr, tmp_bytes, kn, kn, vn, vn, (size_t)q, 63u, ctx->stream));
-        if ((rc = b_redo.alloc(sizeof(int) * q)) || (rc = b_keys.alloc(8 * (size_t)q)) || (rc = b_keys2.alloc(8 * (size_t)q)) || (rc = b_vals.alloc(4 * (size_t)q)) ||
-            (rc = b_order.alloc(4 * (size_t)q)) || (rc = b_tmp.alloc(tmp_bytes)))
-            return rc;
+        if ((rc = b_redo.alloc(sizeof(int) * q))) return rc;
         int* d_redo = b_redo.as<int>();
-        unsigned int* d_order = b_order.as<unsigned int>();
         PCR_HIP(ctx, hipMemsetAsync(d_redo_count, 0, sizeof(unsigned int), ctx->stream));
-        hipLaunchKernelGGL(knn_keys_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, b_keys.as<unsigned long long>(),
-                           b_vals.as<unsigned int>());
-        PCR_HIP(ctx, pcr_sort_pairs(b_tmp.p, tmp_bytes, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(), b_vals.as<unsigned int>(), d_order, (size_t)q, 63u,
-                                    ctx->stream));
         const unsigned gb = (unsigned)((q + 255) / 256);
         if (k <= 8)
-            hipLaunchKernelGGL(knn_tile_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (const unsigned int*)d_order, (long long)q, k, d_idx, d_dist,
-                               d_redo, d_redo_count);
+            hipLaunchKernelGGL(knn_block_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo, d_redo_count);
         else
-            hipLaunchKernelGGL(knn_tile_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (const unsigned int*)d_order, (long long)q, k, d_idx, d_dist,
-                               d_redo, d_redo_count);
+            hipLaunchKernelGGL(knn_block_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo, d_redo_count);
         unsigned int n_redo = 0;
         PCR_HIP(ctx, hipMemcpyAsync(&n_redo, d_redo_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        static const bool dbg = getenv("PCR_KNN_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "pcr_knn: %lld queries, k = %d: %u to the wave-per-query descent\n", (long long)q, k, n_redo);
         if (n_redo)
             hipLaunchKernelGGL(knn_kernel, dim3((n_redo + 3) / 4), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, (const int*)d_redo,
                                (const unsigned int*)d_redo_count);
