@@ -371,22 +371,59 @@ int ensure_pinned(pcr_ctx* ctx, size_t bytes) {
     return PCR_OK;
 }
 
-// Registers pairs[ids[0..m)] in fused stages on ctx.  status[i] < 0 marks pairs that must take the per-pair path instead
-// (PCR_E_UNSUPPORTED as a private "not taken" mark) or that are invalid; results/status of the others are final.
-int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, const pcr_icp_params* params, pcr_icp_result* results,
-                int32_t* status, batch_timing* tm) {
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ns = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
-    };
-    const auto t_begin = now();
+// One sub-batch in flight on one context: begin() packs the clouds, enqueues the whole set-up and the first chunk of ICP passes
+// and returns WITHOUT waiting; end() waits, enqueues further chunks while pairs are still iterating, reads the loop states back
+// and fills the results.  A worker thread keeps two jobs going (on a context and its companion): it packs the next sub-batch
+// while the device works on the current one.  status[i] < 0 marks pairs that must take the per-pair path instead
+// (PCR_E_UNSUPPORTED as a private "not taken" mark) or that are invalid; results/status of the others are final after end().
+struct batch_job {
+    pcr_ctx* ctx;
+    const pcr_pair* pairs = nullptr;
+    std::vector<int64_t> ids;
+    int m = 0;
+    const pcr_icp_params* params = nullptr;
+    pcr_icp_result* results = nullptr;
+    int32_t* status = nullptr;
+    batch_timing* tm = nullptr;
+    bool active = false;           // begin() enqueued work that end() must collect
+    std::vector<char> take;
+    char *hp = nullptr, *hp_dev = nullptr;
+    size_t off_st = 0, off_plan = 0;
+    pcr_batch_pass_args a{};
+    batch_plan* d_plan = nullptr;
+    unsigned int *d_running = nullptr, *h_run = nullptr, *h_run_dev = nullptr;
+    int enq = 0, chunk = 0;
+    std::chrono::steady_clock::time_point t_begin, t_staged, t_enq;
+    dev_block d_in, d_pts, d_keys, d_keys2, d_vals, d_vals2, d_tmp, d_cells, d_blocks, d_small, d_res, d_prev, d_cost, d_items, d_acc, d_st, d_tp;
+    explicit batch_job(pcr_ctx* c)
+        : ctx(c), d_in(c), d_pts(c), d_keys(c), d_keys2(c), d_vals(c), d_vals2(c), d_tmp(c), d_cells(c), d_blocks(c), d_small(c), d_res(c), d_prev(c), d_cost(c),
+          d_items(c), d_acc(c), d_st(c), d_tp(c) {}
+    void release() {   // scratch back to the arena (stream-ordered with what was enqueued)
+        for (dev_block* b : {&d_in, &d_pts, &d_keys, &d_keys2, &d_vals, &d_vals2, &d_tmp, &d_cells, &d_blocks, &d_small, &d_res, &d_prev, &d_cost, &d_items, &d_acc, &d_st, &d_tp}) b->free_now();
+        active = false;
+    }
+    static std::chrono::steady_clock::time_point now() { return std::chrono::steady_clock::now(); }
+    static long long ns(std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+        return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(y - x).count();
+    }
+    int begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_, batch_timing* tm_);
+    int enqueue_chunk();
+    int end();
+};
+
+int batch_job::begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_,
+                     batch_timing* tm_) {
+    pairs = pairs_; m = m_; params = params_; results = results_; status = status_; tm = tm_;
+    ids.assign(ids_, ids_ + m_);
+    active = false;
+    t_begin = now();
     static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     hipSetDevice(ctx->device);
     const int n_clouds = 2 * m;
     // ---- slots: sources first (a source slot index is a query index of the pass kernels), then targets
     std::vector<batch_cloud> cl(n_clouds);
     std::vector<batch_target> tg(m);
-    std::vector<char> take(m, 1);
+    take.assign(m, 1);
     unsigned long long slots = 0;
     for (int half = 0; half < 2; ++half)
         for (int k = 0; k < m; ++k) {
@@ -412,12 +449,13 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     // ---- pinned staging: packed xyz | clouds | targets | T0s ; read-back: states
     const size_t xyz_bytes = (size_t)slots * 12;
     const size_t off_cl = (xyz_bytes + 255) & ~(size_t)255, off_tg = off_cl + ((sizeof(batch_cloud) * n_clouds + 255) & ~(size_t)255);
-    const size_t off_T0 = off_tg + ((sizeof(batch_target) * m + 255) & ~(size_t)255), off_st = off_T0 + ((128 * (size_t)m + 255) & ~(size_t)255);
-    const size_t off_plan = off_st + ((sizeof(pcr_icp_dev_state) * (size_t)m + 255) & ~(size_t)255);
+    const size_t off_T0 = off_tg + ((sizeof(batch_target) * m + 255) & ~(size_t)255);
+    off_st = off_T0 + ((128 * (size_t)m + 255) & ~(size_t)255);
+    off_plan = off_st + ((sizeof(pcr_icp_dev_state) * (size_t)m + 255) & ~(size_t)255);
     const size_t pinned_bytes = off_plan + 256;
     int rc = ensure_pinned(ctx, pinned_bytes);
     if (rc) return rc;
-    char* const hp = (char*)ctx->h_stage;
+    hp = (char*)ctx->h_stage;
     float* const h_xyz = (float*)hp;
     std::vector<double> hi_all(3 * (size_t)n_clouds, 0.0);   // upper corners of the clouds' bounding boxes
     for (int c = 0; c < n_clouds; ++c) {
@@ -508,15 +546,13 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     memcpy(hp + off_tg, tg.data(), sizeof(batch_target) * m);
     double* const h_T0 = (double*)(hp + off_T0);
     for (int k = 0; k < m; ++k) memcpy(h_T0 + 16 * (size_t)k, pairs[ids[k]].T0 ? pairs[ids[k]].T0 : eye, 128);
-    const auto t_staged = now();
+    t_staged = now();
     // ---- device memory
     const unsigned int n_tiles = (unsigned int)(src_slots / 32);
     size_t items_bytes = 0, acc_bytes = 0, sync_word = 0;
     unsigned int cap = 0;
     pcr_grid_batch_scratch_bytes(n_tiles, m, &items_bytes, &acc_bytes, &sync_word, &cap);
     const int n_e = m * PCR_MAX_LEVELS;
-    dev_block d_in(ctx), d_pts(ctx), d_keys(ctx), d_keys2(ctx), d_vals(ctx), d_vals2(ctx), d_tmp(ctx), d_cells(ctx), d_blocks(ctx), d_small(ctx), d_res(ctx),
-        d_prev(ctx), d_cost(ctx), d_items(ctx), d_acc(ctx), d_st(ctx), d_tp(ctx);
     size_t temp_bytes = 0;
     {
         unsigned long long* kn = nullptr;
@@ -540,14 +576,14 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     const double* d_T0 = (const double*)(ds + s_T0);
     unsigned int* d_counts = (unsigned int*)(ds + s_counts);
     unsigned long long* d_coff = (unsigned long long*)(ds + s_coff);
-    batch_plan* d_plan = (batch_plan*)(ds + s_plan);
+    d_plan = (batch_plan*)(ds + s_plan);
     pcr_batch_pair* d_pairs = (pcr_batch_pair*)(ds + s_pairs);
-    unsigned int* d_running = (unsigned int*)(ds + s_run);
+    d_running = (unsigned int*)(ds + s_run);
     hipStream_t st = ctx->stream;
     PCR_HIP(ctx, hipEventRecord(ctx->ev0, st));
     // ---- uploads, keys, sort, records
     // everything crosses PCIe through kernels that read / write the pinned, device-mapped staging block: no copy engine
-    char* hp_dev = nullptr;
+    hp_dev = nullptr;
     PCR_HIP(ctx, hipHostGetDevicePointer((void**)&hp_dev, hp, 0));
     hipLaunchKernelGGL(batch_words_kernel, dim3(8), dim3(256), 0, st, (const unsigned long long*)(hp_dev + off_cl), (unsigned long long*)ds,
                        (unsigned long long)(s_in_end / 8), (unsigned long long)((s_plan + 256) / 8));   // descriptors; counts, offsets and plan zeroed
@@ -574,7 +610,7 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     hipLaunchKernelGGL(batch_insert_blocks_kernel, dim3(8 * ctx->cu_count), dim3(256), 0, st, d_cells.as<pcr_cell_slot>(), d_coff, n_e, d_pairs, d_plan);
     PCR_HIP(ctx, hipGetLastError());
     // ---- ICP
-    pcr_batch_pass_args a{};
+    a = pcr_batch_pass_args{};
     a.pairs = d_pairs;
     a.n_pairs = m;
     a.tile_pair = d_tp.as<unsigned int>();
@@ -595,23 +631,44 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
     a.max_d2 = params->max_d2;
     if ((rc = pcr_grid_batch_init(ctx, &a, d_T0))) return rc;
     PCR_HIP(ctx, hipEventRecord(ctx->ev2, st));
-    const auto t_enq = now();
-    int enq = 0;
-    int chunk = params->min_iter > 2 ? params->min_iter : 2;
+    t_enq = now();
+    enq = 0;
+    chunk = params->min_iter > 2 ? params->min_iter : 2;
     if (ctx->profile) chunk = 1;   // per-launch HIP events: a pass behind the last stop would log empty kernels
-    unsigned int* const h_run = (unsigned int*)ctx->h_pinned;   // (pinned, device-mapped, coherent)
-    unsigned int* h_run_dev = nullptr;
+    h_run = (unsigned int*)ctx->h_pinned;   // (pinned, device-mapped, coherent)
+    h_run_dev = nullptr;
     PCR_HIP(ctx, hipHostGetDevicePointer((void**)&h_run_dev, h_run, 0));
-    while (enq < params->max_iter) {
-        if (chunk > params->max_iter - enq) chunk = params->max_iter - enq;
-        if (chunk > 64) chunk = 64;
-        for (int c = 0; c < chunk; ++c)
-            if ((rc = pcr_grid_batch_pass(ctx, &a, (unsigned int)(enq + c)))) return rc;
-        enq += chunk;
-        hipLaunchKernelGGL(batch_flag_kernel, dim3(1), dim3(1), 0, st, (const unsigned int*)(d_running + (enq - 1)), h_run_dev);
+    // the first chunk of passes goes out with the set-up: begin() returns with everything enqueued and nothing waited for
+    if (params->max_iter > 0) {
+        if ((rc = enqueue_chunk())) return rc;
+    }
+    active = true;
+    return PCR_OK;
+}
+
+int batch_job::enqueue_chunk() {
+    if (chunk > params->max_iter - enq) chunk = params->max_iter - enq;
+    if (chunk > 64) chunk = 64;
+    int rc;
+    for (int c = 0; c < chunk; ++c)
+        if ((rc = pcr_grid_batch_pass(ctx, &a, (unsigned int)(enq + c)))) return rc;
+    enq += chunk;
+    hipLaunchKernelGGL(batch_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, (const unsigned int*)(d_running + (enq - 1)), h_run_dev);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+int batch_job::end() {
+    if (!active) return PCR_OK;
+    const auto t_wait = now();
+    hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    for (;;) {
         PCR_HIP(ctx, hipStreamSynchronize(st));
-        if (*h_run == 0) break;
+        if (params->max_iter <= 0 || *h_run == 0 || enq >= params->max_iter) break;
         if (!ctx->profile) chunk *= 2;
+        if ((rc = enqueue_chunk())) return rc;
     }
     PCR_HIP(ctx, hipEventRecord(ctx->ev1, st));
     const auto t_icp = now();
@@ -657,10 +714,11 @@ int batch_fused(pcr_ctx* ctx, const pcr_pair* pairs, const int64_t* ids, int m, 
         const auto t_end = now();
         tm->ns[0] += ns(t_begin, t_staged);
         tm->ns[1] += ns(t_staged, t_enq);
-        tm->ns[2] += ns(t_enq, t_icp);
+        tm->ns[2] += ns(t_wait, t_icp);
         tm->ns[3] += ns(t_icp, t_end);
         tm->ns[5] += 1;
     }
+    release();
     return PCR_OK;
 }
 
@@ -682,18 +740,34 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
     const char* per_pair_s = getenv("PCR_BATCH_PER_PAIR");   // read per call: the tests switch it
     const bool gated = (params->max_d2 > 0) && std::isfinite(params->max_d2);
     const bool fused = gated && !(per_pair_s && atoi(per_pair_s) != 0);
-    // sub-batches: big enough that a pair's share of the ~20 launches and 2 synchronisations is small, small enough that the
-    // workers' stages (host packing, copies, kernels) overlap each other
+    // Sub-batches: big enough that a pair's share of the ~20 launches and 2 synchronisations is small, small enough that the
+    // workers' stages (host packing, kernels reading the staging buffer over PCIe, sort, grids, passes) overlap each other.
+    // (256 pairs x 20 000 points on 8 contexts, pairs/s: 16 per sub-batch 28-32 k, 32: 37-39 k, 64: 34 k.)
     int64_t sub = 1;
+    const char* sub_s = getenv("PCR_BATCH_SUB");
     if (fused) {
-        const char* s = getenv("PCR_BATCH_SUB");
-        // (256 pairs x 20 000 points on 8 contexts, pairs/s: 16 per sub-batch 28-32 k, 32: 37-39 k, 64: 34 k)
-        sub = s ? atoll(s) : (n_pairs + n_ctx - 1) / n_ctx;
-        if (!s && sub > 64) sub = 64;
+        sub = sub_s ? atoll(sub_s) : (n_pairs + n_ctx - 1) / n_ctx;
+        if (!sub_s && sub > 64) sub = 64;
         if (sub < 4) sub = n_pairs < 4 ? n_pairs : 4;
         if (sub > 256) sub = 256;
     }
-    const int64_t n_sub = (n_pairs + sub - 1) / sub;
+    // PCR_BATCH_PIPELINE=1: a worker keeps TWO sub-batches in flight (its context and the context's companion), packing the next
+    // while the device works on the current one, the first sub-batch of every worker a quarter of the size.  Measured on the
+    // 256 x 20 000 batch (8 workers): 6.8-7.4 ms against 7.0-7.5 ms without -- the batch is bound by the device (PCIe reads of
+    // the key kernels, the sort, the passes), not by the packing, so the default stays the simpler one-at-a-time loop.
+    const char* pipe_s = getenv("PCR_BATCH_PIPELINE");
+    bool pipeline = fused && pipe_s && atoi(pipe_s) != 0;
+    for (int c = 0; c < n_ctx; ++c)
+        if (ctxs[c]->profile) pipeline = false;   // per-launch HIP events (pcr_profile_enable): whole sub-batches on the profiled context
+    // the list of sub-batches [lo, hi)
+    std::vector<std::pair<int64_t, int64_t>> subs;
+    {
+        const int64_t first = (pipeline && !sub_s) ? (sub / 4 < 4 ? (sub < 4 ? sub : 4) : sub / 4) : sub;
+        int64_t lo = 0;
+        for (int w = 0; w < n_ctx && lo < n_pairs && pipeline && first < sub; ++w) { subs.emplace_back(lo, lo + first < n_pairs ? lo + first : n_pairs); lo = subs.back().second; }
+        while (lo < n_pairs) { subs.emplace_back(lo, lo + sub < n_pairs ? lo + sub : n_pairs); lo = subs.back().second; }
+    }
+    const int64_t n_sub = (int64_t)subs.size();
     std::vector<int32_t> status_own;
     int32_t* status = status_out;
     if (!status) { status_own.assign((size_t)n_pairs, 0); status = status_own.data(); }
@@ -709,29 +783,72 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
             hard_error.compare_exchange_strong(expected, rc);
         }
     };
+    // what a sub-batch leaves for the per-pair path (marked PCR_E_UNSUPPORTED by the fused stages, or the whole sub-batch when they failed)
+    auto per_pair_rest = [&](pcr_ctx* ctx, int64_t lo, int64_t hi) {
+        const auto tf0 = std::chrono::steady_clock::now();
+        for (int64_t i = lo; i < hi; ++i) {
+            if (status[i] != PCR_E_UNSUPPORTED) continue;
+            memset(&results[i], 0, sizeof(results[i]));
+            status[i] = run_one_pair(ctx, pairs[i], params, &results[i]);
+            note_error(status[i]);
+        }
+        if (timing) tm.ns[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
+    };
     auto worker = [&](pcr_ctx* ctx) {
         hipSetDevice(ctx->device);
+        pcr_ctx* ctx2 = nullptr;
+        if (pipeline) {
+            if (!ctx->companion && pcr_ctx_create(ctx->device, &ctx->companion) != PCR_OK) ctx->companion = nullptr;
+            ctx2 = ctx->companion;
+            if (ctx2) ctx2->shared_device = 1;
+        }
+        batch_job jobs[2] = {batch_job(ctx), batch_job(ctx2 ? ctx2 : ctx)};
+        int64_t span[2][2] = {{0, 0}, {0, 0}};
+        bool have[2] = {false, false};
         std::vector<int64_t> ids;
-        for (;;) {
+        auto start = [&](int j) {   // takes the next sub-batch and begins it on job j; false: nothing left
             const int64_t s = next.fetch_add(1);
-            if (s >= n_sub) break;
-            const int64_t lo = s * sub, hi = lo + sub < n_pairs ? lo + sub : n_pairs;
+            if (s >= n_sub) return false;
+            const int64_t lo = subs[(size_t)s].first, hi = subs[(size_t)s].second;
+            span[j][0] = lo; span[j][1] = hi;
             ids.clear();
             for (int64_t i = lo; i < hi; ++i) { ids.push_back(i); status[i] = PCR_E_UNSUPPORTED; }
             if (fused) {
-                const int rc = batch_fused(ctx, pairs, ids.data(), (int)ids.size(), params, results, status, timing ? &tm : nullptr);
+                const int rc = jobs[j].begin(pairs, ids.data(), (int)ids.size(), params, results, status, timing ? &tm : nullptr);
                 if (rc) {   // the whole sub-batch failed on the way (out of memory, HIP error): its pairs take the per-pair path
+                    hipStreamSynchronize(jobs[j].ctx->stream);
+                    jobs[j].release();
                     for (int64_t i = lo; i < hi; ++i) status[i] = PCR_E_UNSUPPORTED;
                 }
             }
-            const auto tf0 = std::chrono::steady_clock::now();
-            for (int64_t i = lo; i < hi; ++i) {
-                if (status[i] != PCR_E_UNSUPPORTED) continue;
-                memset(&results[i], 0, sizeof(results[i]));
-                status[i] = run_one_pair(ctx, pairs[i], params, &results[i]);
-                note_error(status[i]);
+            have[j] = true;
+            return true;
+        };
+        auto finish = [&](int j) {
+            if (!have[j]) return;
+            const int64_t lo = span[j][0], hi = span[j][1];
+            if (fused) {
+                const int rc = jobs[j].end();
+                if (rc) {
+                    hipStreamSynchronize(jobs[j].ctx->stream);
+                    jobs[j].release();
+                    for (int64_t i = lo; i < hi; ++i) status[i] = PCR_E_UNSUPPORTED;
+                }
             }
-            if (timing) tm.ns[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
+            per_pair_rest(jobs[j].ctx, lo, hi);
+            have[j] = false;
+        };
+        if (!ctx2) {   // one at a time
+            while (start(0)) finish(0);
+            return;
+        }
+        int cur = 0;
+        if (!start(cur)) return;
+        for (;;) {
+            const bool more = start(cur ^ 1);   // packs and enqueues the next one while the device works on `cur`
+            finish(cur);
+            if (!more) break;
+            cur ^= 1;
         }
     };
     const int n_workers = (int)(n_sub < n_ctx ? n_sub : n_ctx);
@@ -744,9 +861,9 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
     }
     for (int c = 0; c < n_ctx && c < 64; ++c) ctxs[c]->shared_device = was_shared[c];
     if (timing)
-        fprintf(stderr, "pcr_icp_batch: %lld pairs, %lld sub-batches of <= %lld on %d contexts in %.2f ms; per sub-batch: pack %.0f us, set-up enqueue %.0f us, "
-                "ICP (incl. set-up kernels) %.0f us, read-back %.0f us; per-pair path %.0f us in total\n", (long long)n_pairs, (long long)tm.ns[5].load(), (long long)sub,
-                n_workers, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - wall0).count() / 1e3,
+        fprintf(stderr, "pcr_icp_batch: %lld pairs, %lld sub-batches of <= %lld on %d contexts%s in %.2f ms; per sub-batch: pack %.0f us, set-up enqueue %.0f us, "
+                "waiting for the device + further passes %.0f us, read-back %.0f us; per-pair path %.0f us in total\n", (long long)n_pairs, (long long)tm.ns[5].load(), (long long)sub,
+                n_workers, pipeline ? " (two in flight each)" : "", std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - wall0).count() / 1e3,
                 tm.ns[5] ? tm.ns[0] / 1e3 / tm.ns[5] : 0.0, tm.ns[5] ? tm.ns[1] / 1e3 / tm.ns[5] : 0.0, tm.ns[5] ? tm.ns[2] / 1e3 / tm.ns[5] : 0.0,
                 tm.ns[5] ? tm.ns[3] / 1e3 / tm.ns[5] : 0.0, tm.ns[4] / 1e3);
     return hard_error.load();

@@ -122,6 +122,7 @@ struct pcr_ctx {
     hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[4] = {0, 0, 0, 0};
     int prof_passes = 0;
+    pcr_ctx* companion = nullptr;        // second context of the same device (own stream, arena, pinned buffers): pcr_icp_batch keeps two sub-batches going per worker
     int cu_count = 256;
     char name[256] = {0};
     int64_t hbm_bytes = 0;
@@ -149,8 +150,9 @@ struct pcr_dev_block {
     explicit pcr_dev_block(pcr_ctx* c) : ctx(c) {}
     pcr_dev_block(const pcr_dev_block&) = delete;
     pcr_dev_block& operator=(const pcr_dev_block&) = delete;
-    int alloc(size_t b) { bytes = b; return pcr_dev_alloc(ctx, b, &p); }
-    ~pcr_dev_block() { if (p) pcr_dev_free(ctx, p, bytes); }
+    int alloc(size_t b) { free_now(); bytes = b; return pcr_dev_alloc(ctx, b, &p); }
+    void free_now() { if (p) pcr_dev_free(ctx, p, bytes); p = nullptr; bytes = 0; }
+    ~pcr_dev_block() { free_now(); }
     template <typename T> T* as() const { return (T*)p; }
 };
 constexpr int PCR_MAX_LANES = 4;
