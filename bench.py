@@ -45,9 +45,11 @@ N_POINTS = 120_000
 MAX_D2 = 5.0
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix; scripts/mfma_f64_peak measures the achievable rate
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-# algorithmic HBM bytes per correspondence of the grid pass:
-# 32 B source record read + 32 B written back in place + 32 B matched target record + 4 B result slot
-GRID_BYTES_PER_CORR = 100.0
+# algorithmic HBM bytes per correspondence of the grid pass: SURVEY 8d's figure (16 B query + 16 B matched target + 8 B result);
+# the binary64 record layout actually moves 100 B (32 B source record read + 32 B written back in place + 32 B matched target
+# record + 4 B result slot): reported beside it as `frac_f64_layout`
+GRID_BYTES_PER_CORR = 40.0
+GRID_LAYOUT_BYTES_PER_CORR = 100.0
 # VALU issue ceiling (MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 binary32 VALU instruction issues over 2 cycles; binary64
 # ones take twice as long, so this ceiling is generous for this kernel's mix)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2    # wave64 VALU instructions per second: one per SIMD every 2 cycles
@@ -555,6 +557,8 @@ def main():
                 traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": algo_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / dom_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_correspondence": GRID_BYTES_PER_CORR,
+                        "frac_f64_layout": GRID_LAYOUT_BYTES_PER_CORR * n_src / dom_s / 1e9 / HBM_PEAK_GBS,
                         "traffic_source": os.path.relpath(profile_file("pmc_traffic.json"), ROOT) + " (separate rocprofv3 --pmc passes of the same command), not measured in this run",
                         "note": "working set (2 x 3.8 MB) is L2/MALL resident; this kernel is VALU-issue and latency bound, not HBM bound: see roofline_valu"}
         else:
