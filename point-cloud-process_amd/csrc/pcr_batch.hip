@@ -19,7 +19,10 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -75,24 +78,30 @@ __device__ inline int cloud_of_block(const batch_cloud* __restrict__ cl, int n_c
 // of several contexts queue behind each other in the runtime, and sometimes for milliseconds); `xyz_dev` receives the device
 // copy the gather reads later.
 __global__ void __launch_bounds__(SLOT)
-batch_keys_kernel(const float* xyz_host, float* xyz_dev, const batch_cloud* __restrict__ cl, int n_clouds, int mbits,
+batch_keys_kernel(const float* xyz_host, float* xyz_dev, const batch_cloud* __restrict__ cl, int n_clouds, int mbits, unsigned int n_blocks,
                   unsigned long long* __restrict__ keys, unsigned int* __restrict__ vals) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * SLOT + threadIdx.x;
-    const int c = cloud_of_block(cl, n_clouds, (unsigned long long)blockIdx.x * SLOT);
-    const batch_cloud C = cl[c];
+    // A FEW blocks stride over the slots: the kernel is bound by PCIe (56 GB/s: a few thousand loads in flight saturate it), and
+    // launched one block per 256 records its waiting waves fill every wave slot of the chip -- the sort, grid and pass kernels of the
+    // other sub-batches' streams, which should run underneath these reads, then queue behind them.
     const unsigned long long mask = (1ull << mbits) - 1ull;
-    unsigned long long k = mask;   // padding of the slot: behind every point of its cloud (the sort is stable)
-    if (i - C.off < (unsigned long long)C.n) {
-        const float x = xyz_host[3 * i], y = xyz_host[3 * i + 1], z = xyz_host[3 * i + 2];
-        if (xyz_dev != xyz_host) { xyz_dev[3 * i] = x; xyz_dev[3 * i + 1] = y; xyz_dev[3 * i + 2] = z; }
-        bool clamped = false;
-        const unsigned long long cx = (unsigned long long)cell_coord((double)x, C.lo[0], C.inv, &clamped);
-        const unsigned long long cy = (unsigned long long)cell_coord((double)y, C.lo[1], C.inv, &clamped);
-        const unsigned long long cz = (unsigned long long)cell_coord((double)z, C.lo[2], C.inv, &clamped);
-        k = (spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2)) & mask;
+    for (unsigned int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const unsigned long long i = (unsigned long long)blk * SLOT + threadIdx.x;
+        const int c = cloud_of_block(cl, n_clouds, (unsigned long long)blk * SLOT);
+        const batch_cloud C = cl[c];
+        unsigned long long k = mask;   // padding of the slot: behind every point of its cloud (the sort is stable)
+        if (i - C.off < (unsigned long long)C.n) {
+            const float x = xyz_host[3 * i], y = xyz_host[3 * i + 1], z = xyz_host[3 * i + 2];
+            if (xyz_dev != xyz_host) { xyz_dev[3 * i] = x; xyz_dev[3 * i + 1] = y; xyz_dev[3 * i + 2] = z; }
+            bool clamped = false;
+            const unsigned long long cx = (unsigned long long)cell_coord((double)x, C.lo[0], C.inv, &clamped);
+            const unsigned long long cy = (unsigned long long)cell_coord((double)y, C.lo[1], C.inv, &clamped);
+            const unsigned long long cz = (unsigned long long)cell_coord((double)z, C.lo[2], C.inv, &clamped);
+            k = (spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2)) & mask;
+        }
+        keys[i] = ((unsigned long long)c << mbits) | k;
+        vals[i] = (unsigned int)i;
+        __syncthreads();   // (cloud_of_block's shared word is reused by the next round)
     }
-    keys[i] = ((unsigned long long)c << mbits) | k;
-    vals[i] = (unsigned int)i;
 }
 
 __global__ void __launch_bounds__(SLOT)
@@ -283,32 +292,31 @@ batch_insert_cells_kernel(const unsigned long long* __restrict__ keys, const bat
     }
 }
 
-// one thread per slot of the cell pool: an occupied cell registers itself in its 2x2x2 block
-__global__ void __launch_bounds__(256)
-batch_insert_blocks_kernel(const pcr_cell_slot* __restrict__ cell_pool, const unsigned long long* __restrict__ cell_off, int n_e,
-                           const pcr_batch_pair* __restrict__ pairs, const batch_plan* __restrict__ plan) {
+// The thread at the first point of a cell's run looks its (now complete) slot up and registers the cell in its 2x2x2 block: work
+// proportional to the cells, coalesced key reads.  (One thread per slot of the cell POOL -- four fifths of them empty, a binary
+// search per block of 256 to find the slot's table -- took 0.62 of the 5.1 ms of a 256-pair batch.)
+__global__ void __launch_bounds__(SLOT)
+batch_insert_blocks_kernel(const unsigned long long* __restrict__ keys, const batch_cloud* __restrict__ cl, int n_clouds, int m,
+                           const pcr_batch_pair* __restrict__ pairs, unsigned long long first_slot, int mbits, const batch_plan* __restrict__ plan) {
     if (plan->overflow) return;
-    __shared__ int s_e;
-    const unsigned long long nc = plan->used_cells;
-    for (unsigned long long base = (unsigned long long)blockIdx.x * 256; base < nc; base += (unsigned long long)gridDim.x * 256) {
-        __syncthreads();
-        if (threadIdx.x == 0) {   // entry (target, level) of this block of 256 slots: tables are whole blocks
-            int lo = 0, hi = n_e - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (cell_off[mid] <= base) lo = mid;
-                else hi = mid - 1;
-            }
-            s_e = lo;
-        }
-        __syncthreads();
-        const int e = s_e, t = e / PCR_MAX_LEVELS, l = e % PCR_MAX_LEVELS;
-        const pcr_cell_slot c = cell_pool[base + threadIdx.x];
-        if (c.key == PCR_EMPTY_KEY) continue;
-        const pcr_grid_view* gv = &pairs[t].gv;
+    const unsigned long long i = first_slot + (unsigned long long)blockIdx.x * SLOT + threadIdx.x;
+    const int c = cloud_of_block(cl, n_clouds, first_slot + (unsigned long long)blockIdx.x * SLOT);
+    const int t = c - m;
+    const unsigned long long li = i - cl[c].off, n = (unsigned long long)cl[c].n;
+    if (li >= n) return;
+    const unsigned long long mask = (1ull << mbits) - 1ull;
+    const unsigned long long k = (keys[i] & mask) | MORTON_BIAS3;
+    const unsigned long long kp = li > 0 ? (keys[i - 1] & mask) | MORTON_BIAS3 : 0ull;
+    const pcr_grid_view* gv = &pairs[t].gv;
+    const int levels = gv->levels;
+    for (int l = 0; l < levels; ++l) {
+        const unsigned long long ck = k >> (6 * l);
+        if (li != 0 && ck == (kp >> (6 * l))) break;   // not a run start here: not one on any coarser level either
+        const unsigned int X = compact21(ck), Y = compact21(ck >> 1), Z = compact21(ck >> 2);
+        unsigned int cs = 0, ce = 0;
+        if (!lookup_cell(gv->table[l], gv->mask[l], X, Y, Z, &cs, &ce)) continue;
         pcr_block_slot* bt = const_cast<pcr_block_slot*>(gv->btable[l]);
         const unsigned int bmask = gv->bmask[l];
-        const unsigned int X = (unsigned int)(c.key & 0x1fffffull), Y = (unsigned int)((c.key >> 21) & 0x1fffffull), Z = (unsigned int)((c.key >> 42) & 0x1fffffull);
         const unsigned int BX = X >> 1, BY = Y >> 1, BZ = Z >> 1;
         const int child = (int)((X & 1) | ((Y & 1) << 1) | ((Z & 1) << 2));
         const unsigned long long bk = cell_pack(BX, BY, BZ);
@@ -318,10 +326,10 @@ batch_insert_blocks_kernel(const pcr_cell_slot* __restrict__ cell_pool, const un
             if (old == PCR_EMPTY_KEY || old == bk) break;
             b = (b + 1) & bmask;
         }
-        const unsigned int cnt = c.end - c.start;
+        const unsigned int cnt = ce - cs;
         if (cnt >= 0xffffu) atomicOr(&bt[b].flags, 1u);
         bt[b].cnt[child] = (unsigned short)(cnt >= 0xffffu ? 0xffffu : cnt);
-        atomicMin(&bt[b].start, c.start);
+        atomicMin(&bt[b].start, cs);
     }
 }
 
@@ -387,6 +395,14 @@ struct batch_job {
     batch_timing* tm = nullptr;
     bool active = false;           // begin() enqueued work that end() must collect
     std::vector<char> take;
+    std::vector<char> bad_cloud;   // non-finite coordinates met while packing (one flag per cloud: clouds are packed by different threads)
+    std::vector<batch_cloud> cl;
+    std::vector<batch_target> tg;
+    std::vector<double> hi_all;    // upper corners of the clouds' bounding boxes
+    int n_clouds = 0;
+    unsigned long long slots = 0, src_slots = 0;
+    size_t xyz_bytes = 0, off_cl = 0, off_tg = 0, off_T0 = 0;
+    bool nothing = false;          // layout() found nothing for the fused stages
     char *hp = nullptr, *hp_dev = nullptr;
     size_t off_st = 0, off_plan = 0;
     pcr_batch_pass_args a{};
@@ -406,25 +422,36 @@ struct batch_job {
     static long long ns(std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
         return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(y - x).count();
     }
-    int begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_, batch_timing* tm_);
+    // begin() = layout() -> pack_cloud(c) for every cloud c in [0, 2m) (any thread, in any order) -> launch()
+    int layout(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_, batch_timing* tm_);
+    void pack_cloud(int c);
+    int launch();
+    int begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_, batch_timing* tm_) {
+        int rc = layout(pairs_, ids_, m_, params_, results_, status_, tm_);
+        if (rc || nothing) return rc;
+        for (int c = 0; c < n_clouds; ++c) pack_cloud(c);
+        return launch();
+    }
     int enqueue_chunk();
     int end();
 };
 
-int batch_job::begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_,
-                     batch_timing* tm_) {
+int batch_job::layout(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_,
+                      batch_timing* tm_) {
     pairs = pairs_; m = m_; params = params_; results = results_; status = status_; tm = tm_;
     ids.assign(ids_, ids_ + m_);
     active = false;
+    nothing = false;
     t_begin = now();
-    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     hipSetDevice(ctx->device);
-    const int n_clouds = 2 * m;
+    n_clouds = 2 * m;
     // ---- slots: sources first (a source slot index is a query index of the pass kernels), then targets
-    std::vector<batch_cloud> cl(n_clouds);
-    std::vector<batch_target> tg(m);
+    cl.assign(n_clouds, batch_cloud{});
+    tg.assign(m, batch_target{});
     take.assign(m, 1);
-    unsigned long long slots = 0;
+    bad_cloud.assign(n_clouds, 0);
+    hi_all.assign(3 * (size_t)n_clouds, 0.0);
+    slots = 0;
     for (int half = 0; half < 2; ++half)
         for (int k = 0; k < m; ++k) {
             const pcr_pair& P = pairs[ids[k]];
@@ -441,26 +468,32 @@ int batch_job::begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const 
             C.n = n;
             slots += (unsigned long long)((n + SLOT - 1) / SLOT) * SLOT;
         }
-    const unsigned long long src_slots = cl[m].off;
+    src_slots = cl[m].off;
     if (slots == 0 || slots >= (1ull << 31)) {
         for (int k = 0; k < m; ++k) status[ids[k]] = PCR_E_UNSUPPORTED;
+        nothing = true;
         return PCR_OK;
     }
     // ---- pinned staging: packed xyz | clouds | targets | T0s ; read-back: states
-    const size_t xyz_bytes = (size_t)slots * 12;
-    const size_t off_cl = (xyz_bytes + 255) & ~(size_t)255, off_tg = off_cl + ((sizeof(batch_cloud) * n_clouds + 255) & ~(size_t)255);
-    const size_t off_T0 = off_tg + ((sizeof(batch_target) * m + 255) & ~(size_t)255);
+    xyz_bytes = (size_t)slots * 12;
+    off_cl = (xyz_bytes + 255) & ~(size_t)255;
+    off_tg = off_cl + ((sizeof(batch_cloud) * n_clouds + 255) & ~(size_t)255);
+    off_T0 = off_tg + ((sizeof(batch_target) * m + 255) & ~(size_t)255);
     off_st = off_T0 + ((128 * (size_t)m + 255) & ~(size_t)255);
     off_plan = off_st + ((sizeof(pcr_icp_dev_state) * (size_t)m + 255) & ~(size_t)255);
     const size_t pinned_bytes = off_plan + 256;
-    int rc = ensure_pinned(ctx, pinned_bytes);
+    const int rc = ensure_pinned(ctx, pinned_bytes);
     if (rc) return rc;
     hp = (char*)ctx->h_stage;
+    return PCR_OK;
+}
+
+// xyz columns of cloud c -> the staging block, its exact box on the way (float -> double is exact: the box the per-pair path takes)
+void batch_job::pack_cloud(int c) {
     float* const h_xyz = (float*)hp;
-    std::vector<double> hi_all(3 * (size_t)n_clouds, 0.0);   // upper corners of the clouds' bounding boxes
-    for (int c = 0; c < n_clouds; ++c) {
+    {
         const int k = c % m;
-        if (!take[k]) continue;
+        if (!take[k]) return;
         const pcr_pair& P = pairs[ids[k]];
         const bool is_src = c < m;
         const int64_t n = is_src ? P.n_src : P.n_tgt, stride = is_src ? P.stride_src : P.stride_tgt;
@@ -478,9 +511,19 @@ int batch_job::begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const 
             lo[1] = y < lo[1] ? y : lo[1]; hi[1] = y > hi[1] ? y : hi[1];
             lo[2] = z < lo[2] ? z : lo[2]; hi[2] = z > hi[2] ? z : hi[2];
         }
-        if (!finite) { take[k] = 0; continue; }   // (the per-pair path reports it)
+        if (!finite) { bad_cloud[c] = 1; return; }   // (the per-pair path reports it)
         for (int a = 0; a < 3; ++a) { C.lo[a] = (double)lo[a]; hi_all[3 * (size_t)c + a] = (double)hi[a]; }
     }
+}
+
+int batch_job::launch() {
+    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const auto t_packed = now();
+    hipSetDevice(ctx->device);
+    int rc;
+    float* const h_xyz = (float*)hp;
+    for (int k = 0; k < m; ++k)
+        if (bad_cloud[k] || bad_cloud[m + k]) take[k] = 0;
     // grid parameters per pair: the functions the per-pair path uses, on the same boxes
     int mbits = 3;
     for (int k = 0; k < m; ++k) {
@@ -546,7 +589,7 @@ int batch_job::begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const 
     memcpy(hp + off_tg, tg.data(), sizeof(batch_target) * m);
     double* const h_T0 = (double*)(hp + off_T0);
     for (int k = 0; k < m; ++k) memcpy(h_T0 + 16 * (size_t)k, pairs[ids[k]].T0 ? pairs[ids[k]].T0 : eye, 128);
-    t_staged = now();
+    t_staged = t_packed;
     // ---- device memory
     const unsigned int n_tiles = (unsigned int)(src_slots / 32);
     size_t items_bytes = 0, acc_bytes = 0, sync_word = 0;
@@ -590,8 +633,11 @@ int batch_job::begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const 
     const unsigned int blocks_all = (unsigned int)(slots / SLOT), blocks_src = (unsigned int)(src_slots / SLOT), blocks_tgt = blocks_all - blocks_src;
     static const bool use_dma = getenv("PCR_BATCH_DMA") != nullptr;   // A/B: the packed coordinates by the copy engine instead
     if (use_dma) PCR_HIP(ctx, hipMemcpyAsync(d_in.p, h_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(batch_keys_kernel, dim3(blocks_all), dim3(SLOT), 0, st, use_dma ? d_in.as<float>() : (const float*)hp_dev, d_in.as<float>(), d_cl, n_clouds,
-                       mbits, d_keys.as<unsigned long long>(), d_vals.as<unsigned int>());
+    static const int keys_blocks_env = getenv("PCR_BATCH_KEYS_BLOCKS") ? atoi(getenv("PCR_BATCH_KEYS_BLOCKS")) : 0;
+    unsigned int keys_grid = keys_blocks_env > 0 ? (unsigned int)keys_blocks_env : 64u;   // (256 pairs, ms per batch: one block per 256 records 6.4-6.8, 1024 blocks 6.1-6.3, 128: 5.9, 64: 5.4, 32: 5.7, 16: 5.9-6.2)
+    if (keys_grid > blocks_all) keys_grid = blocks_all;
+    hipLaunchKernelGGL(batch_keys_kernel, dim3(keys_grid), dim3(SLOT), 0, st, use_dma ? d_in.as<float>() : (const float*)hp_dev, d_in.as<float>(), d_cl, n_clouds,
+                       mbits, blocks_all, d_keys.as<unsigned long long>(), d_vals.as<unsigned int>());
     // (rocPRIM's default configuration = merge sort at this size.  Onesweep is faster for one sort of 1.3 M pairs alone -- 126 against
     // 190 us -- but not with eight sub-batches' sorts in flight together, and it adds a dozen 17-us fills per sort.)
     PCR_HIP(ctx, rocprim::radix_sort_pairs(d_tmp.p, temp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned int>(),
@@ -607,7 +653,9 @@ int batch_job::begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const 
     if (blocks_tgt)
         hipLaunchKernelGGL(batch_insert_cells_kernel, dim3(blocks_tgt), dim3(SLOT), 0, st, d_keys2.as<unsigned long long>(), d_cl, n_clouds, m, d_pairs, src_slots, mbits,
                            d_plan);
-    hipLaunchKernelGGL(batch_insert_blocks_kernel, dim3(8 * ctx->cu_count), dim3(256), 0, st, d_cells.as<pcr_cell_slot>(), d_coff, n_e, d_pairs, d_plan);
+    if (blocks_tgt)
+        hipLaunchKernelGGL(batch_insert_blocks_kernel, dim3(blocks_tgt), dim3(SLOT), 0, st, d_keys2.as<unsigned long long>(), d_cl, n_clouds, m, d_pairs, src_slots, mbits,
+                           d_plan);
     PCR_HIP(ctx, hipGetLastError());
     // ---- ICP
     a = pcr_batch_pass_args{};
@@ -740,38 +788,23 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
     const char* per_pair_s = getenv("PCR_BATCH_PER_PAIR");   // read per call: the tests switch it
     const bool gated = (params->max_d2 > 0) && std::isfinite(params->max_d2);
     const bool fused = gated && !(per_pair_s && atoi(per_pair_s) != 0);
-    // Sub-batches: big enough that a pair's share of the ~20 launches and 2 synchronisations is small, small enough that the
-    // workers' stages (host packing, kernels reading the staging buffer over PCIe, sort, grids, passes) overlap each other.
-    // (256 pairs x 20 000 points on 8 contexts, pairs/s: 16 per sub-batch 28-32 k, 32: 37-39 k, 64: 34 k.)
+    // Sub-batches.  The device does a sub-batch's stages the more efficiently the bigger it is (256 pairs x 20 000 points as ONE
+    // sub-batch: 5.1 ms of kernels, 2.2 of them the key kernel's PCIe reads; as eight of 32 on eight streams: 7.0-7.5 ms wall), but
+    // a sub-batch packed by one thread keeps the device waiting (12 ms for 256 pairs).  So the n_ctx threads pack ONE sub-batch
+    // TOGETHER (a cloud each, from a shared counter); the thread that packs its last cloud launches it on the sub-batch's own
+    // context and waits for it, while the others already pack the next one -- whose key kernel then reads over PCIe while the
+    // first one's sort, grids and passes run.
     int64_t sub = 1;
     const char* sub_s = getenv("PCR_BATCH_SUB");
     if (fused) {
-        sub = sub_s ? atoll(sub_s) : (n_pairs + n_ctx - 1) / n_ctx;
-        if (!sub_s && sub > 64) sub = 64;
-        if (sub < 4) sub = n_pairs < 4 ? n_pairs : 4;
-        if (sub > 256) sub = 256;
+        sub = sub_s ? atoll(sub_s) : (n_ctx > 1 ? 64 : n_pairs);   // (256 pairs on 8 threads, ms: 32 or 64 per sub-batch 4.8, 128: 5.6, 256: 7.0)
+        if (sub < 1) sub = 1;
+        if (sub > 512) sub = 512;
     }
-    // PCR_BATCH_PIPELINE=1: a worker keeps TWO sub-batches in flight (its context and the context's companion), packing the next
-    // while the device works on the current one, the first sub-batch of every worker a quarter of the size.  Measured on the
-    // 256 x 20 000 batch (8 workers): 6.8-7.4 ms against 7.0-7.5 ms without -- the batch is bound by the device (PCIe reads of
-    // the key kernels, the sort, the passes), not by the packing, so the default stays the simpler one-at-a-time loop.
-    const char* pipe_s = getenv("PCR_BATCH_PIPELINE");
-    bool pipeline = fused && pipe_s && atoi(pipe_s) != 0;
-    for (int c = 0; c < n_ctx; ++c)
-        if (ctxs[c]->profile) pipeline = false;   // per-launch HIP events (pcr_profile_enable): whole sub-batches on the profiled context
-    // the list of sub-batches [lo, hi)
-    std::vector<std::pair<int64_t, int64_t>> subs;
-    {
-        const int64_t first = (pipeline && !sub_s) ? (sub / 4 < 4 ? (sub < 4 ? sub : 4) : sub / 4) : sub;
-        int64_t lo = 0;
-        for (int w = 0; w < n_ctx && lo < n_pairs && pipeline && first < sub; ++w) { subs.emplace_back(lo, lo + first < n_pairs ? lo + first : n_pairs); lo = subs.back().second; }
-        while (lo < n_pairs) { subs.emplace_back(lo, lo + sub < n_pairs ? lo + sub : n_pairs); lo = subs.back().second; }
-    }
-    const int64_t n_sub = (int64_t)subs.size();
+    const int64_t n_sub = (n_pairs + sub - 1) / sub;
     std::vector<int32_t> status_own;
     int32_t* status = status_out;
     if (!status) { status_own.assign((size_t)n_pairs, 0); status = status_own.data(); }
-    std::atomic<int64_t> next(0);
     std::atomic<int> hard_error(PCR_OK);
     const bool timing = getenv("PCR_BATCH_TIMING") != nullptr;   // read per call
     batch_timing tm;
@@ -794,76 +827,92 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
         }
         if (timing) tm.ns[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
     };
-    auto worker = [&](pcr_ctx* ctx) {
-        hipSetDevice(ctx->device);
-        pcr_ctx* ctx2 = nullptr;
-        if (pipeline) {
-            if (!ctx->companion && pcr_ctx_create(ctx->device, &ctx->companion) != PCR_OK) ctx->companion = nullptr;
-            ctx2 = ctx->companion;
-            if (ctx2) ctx2->shared_device = 1;
-        }
-        batch_job jobs[2] = {batch_job(ctx), batch_job(ctx2 ? ctx2 : ctx)};
-        int64_t span[2][2] = {{0, 0}, {0, 0}};
-        bool have[2] = {false, false};
-        std::vector<int64_t> ids;
-        auto start = [&](int j) {   // takes the next sub-batch and begins it on job j; false: nothing left
-            const int64_t s = next.fetch_add(1);
-            if (s >= n_sub) return false;
-            const int64_t lo = subs[(size_t)s].first, hi = subs[(size_t)s].second;
-            span[j][0] = lo; span[j][1] = hi;
-            ids.clear();
-            for (int64_t i = lo; i < hi; ++i) { ids.push_back(i); status[i] = PCR_E_UNSUPPORTED; }
-            if (fused) {
-                const int rc = jobs[j].begin(pairs, ids.data(), (int)ids.size(), params, results, status, timing ? &tm : nullptr);
-                if (rc) {   // the whole sub-batch failed on the way (out of memory, HIP error): its pairs take the per-pair path
-                    hipStreamSynchronize(jobs[j].ctx->stream);
-                    jobs[j].release();
-                    for (int64_t i = lo; i < hi; ++i) status[i] = PCR_E_UNSUPPORTED;
-                }
+    for (int64_t i = 0; i < n_pairs; ++i) status[i] = PCR_E_UNSUPPORTED;
+    if (!fused) {   // per-pair path: a pool of workers, one context each, pairs from a shared counter
+        std::atomic<int64_t> next(0);
+        auto worker = [&](pcr_ctx* ctx) {
+            hipSetDevice(ctx->device);
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n_pairs) break;
+                per_pair_rest(ctx, i, i + 1);
             }
-            have[j] = true;
-            return true;
         };
-        auto finish = [&](int j) {
-            if (!have[j]) return;
-            const int64_t lo = span[j][0], hi = span[j][1];
-            if (fused) {
-                const int rc = jobs[j].end();
-                if (rc) {
-                    hipStreamSynchronize(jobs[j].ctx->stream);
-                    jobs[j].release();
-                    for (int64_t i = lo; i < hi; ++i) status[i] = PCR_E_UNSUPPORTED;
-                }
-            }
-            per_pair_rest(jobs[j].ctx, lo, hi);
-            have[j] = false;
-        };
-        if (!ctx2) {   // one at a time
-            while (start(0)) finish(0);
-            return;
+        const int n_workers = (int)(n_pairs < n_ctx ? n_pairs : n_ctx);
+        if (n_workers <= 1) worker(ctxs[0]);
+        else {
+            std::vector<std::thread> pool;
+            for (int c = 0; c < n_workers; ++c) pool.emplace_back(worker, ctxs[c]);
+            for (auto& t : pool) t.join();
         }
-        int cur = 0;
-        if (!start(cur)) return;
-        for (;;) {
-            const bool more = start(cur ^ 1);   // packs and enqueues the next one while the device works on `cur`
-            finish(cur);
-            if (!more) break;
-            cur ^= 1;
-        }
-    };
-    const int n_workers = (int)(n_sub < n_ctx ? n_sub : n_ctx);
-    if (n_workers <= 1) {
-        worker(ctxs[0]);
     } else {
-        std::vector<std::thread> pool;
-        for (int c = 0; c < n_workers; ++c) pool.emplace_back(worker, ctxs[c]);
-        for (auto& t : pool) t.join();
+        struct sub_state {
+            std::unique_ptr<batch_job> job;
+            int64_t lo = 0, hi = 0;
+            std::vector<int64_t> ids;
+            std::once_flag once;
+            std::atomic<int> packed{0};
+            std::atomic<int> finished{0};
+            int rc = PCR_OK;
+        };
+        std::vector<sub_state> subs((size_t)n_sub);
+        std::vector<int64_t> task0((size_t)n_sub + 1, 0);   // tasks = (sub-batch, cloud), sub-batch after sub-batch
+        for (int64_t j = 0; j < n_sub; ++j) {
+            sub_state& S = subs[(size_t)j];
+            S.lo = j * sub;
+            S.hi = S.lo + sub < n_pairs ? S.lo + sub : n_pairs;
+            for (int64_t i = S.lo; i < S.hi; ++i) S.ids.push_back(i);
+            S.job.reset(new batch_job(ctxs[j % n_ctx]));   // sub-batch j runs on context j mod n_ctx, after sub-batch j - n_ctx
+            task0[(size_t)j + 1] = task0[(size_t)j] + 2 * (S.hi - S.lo);
+        }
+        std::atomic<int64_t> next(0);
+        const int64_t n_tasks = task0[(size_t)n_sub];
+        auto worker = [&]() {
+            for (;;) {
+                const int64_t t = next.fetch_add(1);
+                if (t >= n_tasks) break;
+                int64_t j = (int64_t)(std::upper_bound(task0.begin(), task0.end(), t) - task0.begin()) - 1;
+                sub_state& S = subs[(size_t)j];
+                const int c = (int)(t - task0[(size_t)j]);
+                batch_job& J = *S.job;
+                std::call_once(S.once, [&] {
+                    if (j >= n_ctx)   // the context (stream, staging block, arena) is still the earlier sub-batch's until that one has finished
+                        while (!subs[(size_t)(j - n_ctx)].finished.load(std::memory_order_acquire)) std::this_thread::yield();
+                    S.rc = J.layout(pairs, S.ids.data(), (int)S.ids.size(), params, results, status, timing ? &tm : nullptr);
+                });
+                const bool usable = S.rc == PCR_OK && !J.nothing;
+                if (usable) J.pack_cloud(c);
+                if (S.packed.fetch_add(1, std::memory_order_acq_rel) + 1 < 2 * (int)S.ids.size()) continue;
+                // this thread packed the sub-batch's last cloud: it launches it, waits for it and finishes it
+                hipSetDevice(J.ctx->device);
+                int rc = S.rc;
+                if (usable) {
+                    rc = J.launch();
+                    if (rc == PCR_OK) rc = J.end();
+                }
+                if (rc) {   // the whole sub-batch failed on the way (out of memory, HIP error): its pairs take the per-pair path
+                    hipStreamSynchronize(J.ctx->stream);
+                    J.release();
+                    for (int64_t i = S.lo; i < S.hi; ++i) status[i] = PCR_E_UNSUPPORTED;
+                }
+                per_pair_rest(J.ctx, S.lo, S.hi);
+                S.finished.store(1, std::memory_order_release);
+            }
+        };
+        int n_workers = n_ctx;
+        if ((int64_t)n_workers > n_tasks) n_workers = (int)n_tasks;
+        if (n_workers <= 1) worker();
+        else {
+            std::vector<std::thread> pool;
+            for (int c = 0; c < n_workers; ++c) pool.emplace_back(worker);
+            for (auto& t : pool) t.join();
+        }
     }
     for (int c = 0; c < n_ctx && c < 64; ++c) ctxs[c]->shared_device = was_shared[c];
     if (timing)
-        fprintf(stderr, "pcr_icp_batch: %lld pairs, %lld sub-batches of <= %lld on %d contexts%s in %.2f ms; per sub-batch: pack %.0f us, set-up enqueue %.0f us, "
+        fprintf(stderr, "pcr_icp_batch: %lld pairs, %lld sub-batches of <= %lld, %d threads in %.2f ms; per sub-batch: layout + packing (all threads) %.0f us, launch %.0f us, "
                 "waiting for the device + further passes %.0f us, read-back %.0f us; per-pair path %.0f us in total\n", (long long)n_pairs, (long long)tm.ns[5].load(), (long long)sub,
-                n_workers, pipeline ? " (two in flight each)" : "", std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - wall0).count() / 1e3,
+                n_ctx, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - wall0).count() / 1e3,
                 tm.ns[5] ? tm.ns[0] / 1e3 / tm.ns[5] : 0.0, tm.ns[5] ? tm.ns[1] / 1e3 / tm.ns[5] : 0.0, tm.ns[5] ? tm.ns[2] / 1e3 / tm.ns[5] : 0.0,
                 tm.ns[5] ? tm.ns[3] / 1e3 / tm.ns[5] : 0.0, tm.ns[4] / 1e3);
     return hard_error.load();

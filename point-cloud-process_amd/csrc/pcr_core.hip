@@ -84,8 +84,6 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
 
 int pcr_ctx_destroy(pcr_ctx* c) {
     if (!c) return PCR_OK;
-    if (c->companion) pcr_ctx_destroy(c->companion);
-    c->companion = nullptr;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (void* a : c->arenas) hipFree(a);

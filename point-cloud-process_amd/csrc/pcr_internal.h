@@ -122,7 +122,6 @@ struct pcr_ctx {
     hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[4] = {0, 0, 0, 0};
     int prof_passes = 0;
-    pcr_ctx* companion = nullptr;        // second context of the same device (own stream, arena, pinned buffers): pcr_icp_batch keeps two sub-batches going per worker
     int cu_count = 256;
     char name[256] = {0};
     int64_t hbm_bytes = 0;
