@@ -801,7 +801,10 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
         if (sub < 1) sub = 1;
         if (sub > 512) sub = 512;
     }
-    const int64_t n_sub = (n_pairs + sub - 1) / sub;
+    // (a smaller first sub-batch -- device work after a quarter of a packing time -- measured 5.4 against 4.8-5.1 ms: not adopted)
+    std::vector<int64_t> bounds(1, 0);
+    while (bounds.back() < n_pairs) bounds.push_back(bounds.back() + sub < n_pairs ? bounds.back() + sub : n_pairs);
+    const int64_t n_sub = (int64_t)bounds.size() - 1;
     std::vector<int32_t> status_own;
     int32_t* status = status_out;
     if (!status) { status_own.assign((size_t)n_pairs, 0); status = status_own.data(); }
@@ -859,8 +862,8 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
         std::vector<int64_t> task0((size_t)n_sub + 1, 0);   // tasks = (sub-batch, cloud), sub-batch after sub-batch
         for (int64_t j = 0; j < n_sub; ++j) {
             sub_state& S = subs[(size_t)j];
-            S.lo = j * sub;
-            S.hi = S.lo + sub < n_pairs ? S.lo + sub : n_pairs;
+            S.lo = bounds[(size_t)j];
+            S.hi = bounds[(size_t)j + 1];
             for (int64_t i = S.lo; i < S.hi; ++i) S.ids.push_back(i);
             S.job.reset(new batch_job(ctxs[j % n_ctx]));   // sub-batch j runs on context j mod n_ctx, after sub-batch j - n_ctx
             task0[(size_t)j + 1] = task0[(size_t)j] + 2 * (S.hi - S.lo);
