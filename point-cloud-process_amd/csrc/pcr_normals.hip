@@ -246,12 +246,12 @@ int pcr_normals(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double* normals_out
     }
 #undef PCR_NK
     PCR_HIP(ctx, hipGetLastError());
-    std::vector<int32_t> nbr((size_t)k * n);
-    std::vector<double> ev(3 * (size_t)n);
+    // eigenvalues and neighbour lists cross PCIe only when the caller asked for them, and then straight into the caller's arrays
+    // (they went through two host vectors before: a page-faulting allocation and a second copy of 5 MB per 120 000 points)
     unsigned int n_redo = 0;
     PCR_HIP(ctx, hipMemcpyAsync(normals_out, d_nrm, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipMemcpyAsync(ev.data(), d_ev, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipMemcpyAsync(nbr.data(), d_nbr, sizeof(int) * (size_t)k * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (eigvals_out) PCR_HIP(ctx, hipMemcpyAsync(eigvals_out, d_ev, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (neighbours_out) PCR_HIP(ctx, hipMemcpyAsync(neighbours_out, d_nbr, sizeof(int) * (size_t)k * n, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipMemcpyAsync(&n_redo, d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rc = PCR_OK;
@@ -283,9 +283,9 @@ int pcr_normals(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double* normals_out
             for (int c = 0; c < 3; ++c) m[c] /= cnt;
             double S[6] = {0, 0, 0, 0, 0, 0};
             for (int j = 0; j < k; ++j) {
-                if (kdist[(size_t)r * k + j] >= 1e10) { nbr[(size_t)rows[r] * k + j] = -1; continue; }
+                if (kdist[(size_t)r * k + j] >= 1e10) { if (neighbours_out) neighbours_out[(size_t)rows[r] * k + j] = -1; continue; }
                 const int id = kidx[(size_t)r * k + j];
-                nbr[(size_t)rows[r] * k + j] = id;
+                if (neighbours_out) neighbours_out[(size_t)rows[r] * k + j] = id;
                 const double x = xyz[3 * (size_t)id] - m[0], y = xyz[3 * (size_t)id + 1] - m[1], z = xyz[3 * (size_t)id + 2] - m[2];
                 S[0] += x * x; S[1] += x * y; S[2] += x * z; S[3] += y * y; S[4] += y * z; S[5] += z * z;
             }
@@ -295,12 +295,10 @@ int pcr_normals(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double* normals_out
             sym3_eig(S, e3, V);
             for (int c = 0; c < 3; ++c) {
                 normals_out[3 * (size_t)rows[r] + c] = V[3 * c + 2];
-                ev[3 * (size_t)rows[r] + c] = e3[c];
+                if (eigvals_out) eigvals_out[3 * (size_t)rows[r] + c] = e3[c];
             }
         }
     }
-    if (eigvals_out) memcpy(eigvals_out, ev.data(), sizeof(double) * 3 * n);
-    if (neighbours_out) memcpy(neighbours_out, nbr.data(), sizeof(int32_t) * (size_t)k * n);
     pcr_dev_free(ctx, d_nrm, sizeof(double) * 3 * n);
     pcr_dev_free(ctx, d_ev, sizeof(double) * 3 * n);
     pcr_dev_free(ctx, d_nbr, sizeof(int) * (size_t)k * n);

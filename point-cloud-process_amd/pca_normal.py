@@ -42,9 +42,10 @@ def estimate_normals(points, k=5, ctx=None, return_details=False):
         cloud = own = DeviceCloud.upload(points_of(points), ctx)
     n = cloud.n
     normals = np.empty((n, 3), dtype=np.float64)
-    ev = np.empty((n, 3), dtype=np.float64)
-    nbr = np.empty((n, int(k)), dtype=np.int32)
-    L.check(L.lib().pcr_normals(ctx.handle, cloud.handle, int(k), L.dptr(normals), L.dptr(ev), L.iptr(nbr)), ctx.handle)
+    ev = np.empty((n, 3), dtype=np.float64) if return_details else None       # (only read back when asked for)
+    nbr = np.empty((n, int(k)), dtype=np.int32) if return_details else None
+    L.check(L.lib().pcr_normals(ctx.handle, cloud.handle, int(k), L.dptr(normals), L.dptr(ev) if return_details else None,
+                                L.iptr(nbr) if return_details else None), ctx.handle)
     if own is not None:
         own.free()
     return (normals, ev, nbr) if return_details else normals
