@@ -226,11 +226,6 @@ radius_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq
 
 
 
-// (Wave tiles for this batch -- queries along the Morton curve, 64 per wave, the cells of their common box staged into LDS once,
-// a ball-driven second pass, adaptive lane groups -- were built and measured this round against the kernel below on the same
-// box: 120 000 x 120 000, k = 8: 6.5 ms against 3.0; the cloud against itself 1.50 against 1.19; normals 2.6 against 1.8.  A
-// common box holds 3-5 x the candidates of a query's own 27 cells, every staged point costs every lane ~100 cycles of binary64
-// distance + list insertion, and one wave serving 64 queries of very different needs is the kernel's tail.)
 // Batched k-NN, first stage (k <= 16): ONE LANE per query scans the 3x3x3 block of cells around it and keeps the k best
 // (d2, index) pairs in registers, sorted.  The block covers every point within the distance from the query to the
 // block's nearest face (>= one cell), so the result is exact when the k-th distance does not exceed that; level 0 is
@@ -243,8 +238,12 @@ radius_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq
 template <int K>
 __global__ void __launch_bounds__(256)
 knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq, int k, int* __restrict__ idx_out,
-                 double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count) {
-    const long long qi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                 double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count,
+                 const int* __restrict__ todo /* query ids to do (what the wave tiles left), or null: all */, const unsigned int* __restrict__ todo_count,
+                 int lv_cap /* highest level this launch may climb to */) {
+    const long long ti = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_do = (todo && todo_count) ? (long long)*todo_count : nq;   // (a list without a count: all nq entries, e.g. the curve order)
+    const long long qi = ti < n_do ? (todo ? (long long)todo[ti] : ti) : nq;
     bool proven = false;
     double bd[K];
     long long bi[K];
@@ -255,7 +254,7 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
         const int cy = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
         const int cz = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
         // levels 0, 1 and -- only where the surroundings are sparse (few points met one level down) -- 2 and 3
-        const int max_level = gv.levels - 1 < PCR_KNN_LV ? gv.levels - 1 : PCR_KNN_LV;
+        const int max_level = min(gv.levels - 1 < PCR_KNN_LV ? gv.levels - 1 : PCR_KNN_LV, lv_cap);
         unsigned int met = 0;
         for (int level = 0; level <= max_level && !clamped && !proven && (level < 2 || met <= 192u); ++level) {
             met = 0;
@@ -338,6 +337,254 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batched k-NN (k <= 16), second stage: ONE QUERY PER WAVE (LPQ = 64 lanes per query; the kernel is written for any power of two,
+// 64 / LPQ queries sharing a box).  The wave stages the cells of the query's box into its LDS slice, every lane scans its share
+// of the staged points keeping its k best in registers, and the lanes' lists meet by shuffle exchanges.  Pass 0: the query's own
+// level-0 cell and one ring.  A query whose k-th distance lies inside the ball the staged box certainly covers is proven; one
+// that found k points knows a ball that holds its answer, and the next pass stages the box of that ball -- in cells of the
+// finest level that keeps the box small --; one that still lacks k points asks for rings of 4, 16, 64 ... cells.
+// Measured on one box (PCR_KNN_NO_TILES=1 = round 2's path: lane-per-query scan at every level, then the wave-per-query
+// descent), 120 000-point scan: 120 000 other queries, k = 8: 1.76 against 3.05 ms; 20 000 off-surface queries: 1.5 against
+// 9.7 ms (k = 8), 2.8 against 17 (k = 16) -- nothing reaches the descent any more, whose k full descents per query took
+// milliseconds for a handful of far-out queries --; the scan against itself: a tie (1.09 / 1.14 ms at k = 8).
+// Tiles of SEVERAL queries in curve order (64 x 1 lane, then 16 x 4 -> 4 x 16 -> 1 x 64 in three stages) were built first: the
+// one-lane version lost outright (6.5 against 3.0 ms), the three-stage one won on other-cloud queries (1.56 ms) but lost 2 x on
+// small k against itself (0.92 against 0.51 ms at k = 3: a sort and three launches in front of work the first scan does in 0.5 ms).
+constexpr int KT_PTS = 384;         // points staged per round
+constexpr int KT_LIST = 512;        // occupied cells of a tile's box
+constexpr int KT_BOX = 2048;        // cells of a tile's box (occupied or not)
+
+struct knn_tile_lds {
+    double x[KT_PTS], y[KT_PTS], z[KT_PTS];
+    int id[KT_PTS];
+    unsigned int c_start[KT_LIST], c_pre[KT_LIST + 1];
+};
+__device__ static inline void kt_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ static inline int kt_wave_min(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ static inline int kt_wave_max(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// LPQ lanes per query (64 / LPQ queries per wave), PASSES passes of at most ROUNDS staging rounds.  `order`: the query ids to do, n
+// of them (n = *count_p when count_p is given: the list the first stage left).
+template <int K, int LPQ, int PASSES, int ROUNDS>
+__device__ static void knn_tile_one(const pcr_grid_view& gv, knn_tile_lds* L, const int lane, const long long tile, const long long nq,
+                                    const double* __restrict__ queries, const unsigned int* __restrict__ order, int k, int* __restrict__ idx_out,
+                                    double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count) {
+    constexpr int QPT = 64 / LPQ;
+    const int sub = lane & (LPQ - 1);
+    const long long slot = tile * QPT + (lane / LPQ);
+    const bool valid = slot < nq;
+    const long long qi = valid ? (long long)order[slot] : 0;
+    double ax = 0, ay = 0, az = 0;
+    bool clamped = false;
+    int c0[3] = {0, 0, 0};
+    if (valid) {
+        ax = queries[3 * qi]; ay = queries[3 * qi + 1]; az = queries[3 * qi + 2];
+        c0[0] = cell_coord(ax, gv.lo[0], gv.inv_cell0, &clamped);
+        c0[1] = cell_coord(ay, gv.lo[1], gv.inv_cell0, &clamped);
+        c0[2] = cell_coord(az, gv.lo[2], gv.inv_cell0, &clamped);
+    }
+    bool open = valid && !clamped;     // still to be proven (the four lanes of a query agree)
+    bool proven = false;
+    double bd[K];
+    long long bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bd[j] = DBL_MAX; bi[j] = 0x7fffffffffffffffll; }
+    const int top = gv.levels - 1;
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (!__ballot(open)) break;
+        int lo0[3], hi0[3];   // this query's box in level-0 cell coordinates
+        {
+            double kth = DBL_MAX;
+#pragma unroll
+            for (int j = 0; j < K; ++j) kth = (j == k - 1) ? bd[j] : kth;
+            const double a[3] = {ax, ay, az};
+            if (pass > 0 && kth < DBL_MAX) {
+                const double r = sqrt(kth) * (1.0 + 1e-9) + gv.cell0 * 1e-6;
+                bool cl = false;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    lo0[d] = cell_coord(a[d] - r, gv.lo[d], gv.inv_cell0, &cl);
+                    hi0[d] = cell_coord(a[d] + r, gv.lo[d], gv.inv_cell0, &cl);
+                }
+            } else {
+                const int ring = 1 << (2 * pass);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { lo0[d] = max(c0[d] - ring, 0); hi0[d] = min(c0[d] + ring, (int)PCR_COORD_MAX); }
+            }
+        }
+        int w0[3], w1[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            w0[d] = kt_wave_min(open ? lo0[d] : 0x7fffffff);
+            w1[d] = kt_wave_max(open ? hi0[d] : 0);
+        }
+        int level = 0;
+        long long ncell = 0;
+        for (; level <= top; ++level) {
+            ncell = (long long)((w1[0] >> (2 * level)) - (w0[0] >> (2 * level)) + 1) * ((w1[1] >> (2 * level)) - (w0[1] >> (2 * level)) + 1) *
+                    ((w1[2] >> (2 * level)) - (w0[2] >> (2 * level)) + 1);
+            if (ncell <= KT_BOX) break;
+        }
+        if (level > top) break;   // the tile's queries are spread too far for a common box (a jump of the curve)
+        const int x0 = w0[0] >> (2 * level), y0 = w0[1] >> (2 * level), z0 = w0[2] >> (2 * level);
+        const int dx = (w1[0] >> (2 * level)) - x0 + 1, dy = (w1[1] >> (2 * level)) - y0 + 1;
+        const int b1[3] = {w1[0] >> (2 * level), w1[1] >> (2 * level), w1[2] >> (2 * level)};
+        // ---- directory: occupied cells of the box and the exclusive prefix of their point counts
+        unsigned int n_list = 0, n_pts = 0;
+        bool too_much = false;
+        for (int base = 0; base < (int)ncell; base += 64) {
+            const int c = base + lane;
+            unsigned int cs = 0, ce = 0;
+            bool found = false;
+            if (c < (int)ncell) {
+                const int X = x0 + c % dx, Y = y0 + (c / dx) % dy, Z = z0 + c / (dx * dy);
+                found = lookup_cell(gv.table[level], gv.mask[level], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &cs, &ce);
+            }
+            const unsigned long long fm = __ballot(found);
+            unsigned int cnt = found ? ce - cs : 0u, inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned int o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            const unsigned int li = n_list + (unsigned int)__popcll(fm & ((1ull << lane) - 1ull));
+            if (found && li < KT_LIST) { L->c_start[li] = cs; L->c_pre[li] = n_pts + inc - cnt; }
+            n_list += (unsigned int)__popcll(fm);
+            n_pts += __shfl(inc, 63, 64);
+            if (n_list > KT_LIST) { too_much = true; break; }
+        }
+        if (too_much || n_pts > (unsigned int)(ROUNDS * KT_PTS)) break;   // too much for this stage
+        if (lane == 0) L->c_pre[n_list] = n_pts;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { bd[j] = DBL_MAX; bi[j] = 0x7fffffffffffffffll; }
+        // ---- rounds: stage up to KT_PTS points; every lane scans a quarter of them for its query
+        for (unsigned int r0 = 0; r0 < n_pts; r0 += KT_PTS) {
+            const unsigned int cnt = min(n_pts - r0, (unsigned int)KT_PTS);
+            kt_wave_sync();   // the directory (first round) / the last scan's reads are done
+            for (unsigned int t = lane; t < cnt; t += 64) {
+                const unsigned int j = r0 + t;
+                unsigned int lo = 0, hi = n_list - 1;   // last cell whose prefix <= j
+                while (lo < hi) {
+                    const unsigned int mid = (lo + hi + 1) >> 1;
+                    if (L->c_pre[mid] <= j) lo = mid;
+                    else hi = mid - 1;
+                }
+                const pcr_pt rec = gv.pts[L->c_start[lo] + (j - L->c_pre[lo])];
+                L->x[t] = rec.x; L->y[t] = rec.y; L->z[t] = rec.z; L->id[t] = (int)rec.id;
+            }
+            kt_wave_sync();
+            if (open) {
+                for (unsigned int t = sub; t < cnt; t += LPQ) {
+                    const double ex = ax - L->x[t], ey = ay - L->y[t], ez = az - L->z[t];
+                    double d2 = (ex * ex + ey * ey) + ez * ez;
+                    long long id = (long long)L->id[t];
+                    if (!better(d2, id, bd[K - 1], bi[K - 1])) continue;
+#pragma unroll
+                    for (int u = 0; u < K; ++u) {
+                        if (better(d2, id, bd[u], bi[u])) {
+                            const double td = bd[u]; const long long ti = bi[u];
+                            bd[u] = d2; bi[u] = id;
+                            d2 = td; id = ti;
+                        }
+                    }
+                }
+            }
+        }
+        kt_wave_sync();
+        // ---- the LPQ lists of a query meet: exchange with lane ^ 1, lane ^ 2, ...; every entry of the partner's list is inserted
+        // (disjoint quarters: no duplicates), so all four lanes end with the same k best
+#pragma unroll
+        for (int xm = 1; xm < LPQ; xm <<= 1) {
+            double od[K];
+            long long oi[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) { od[j] = __shfl_xor(bd[j], xm, 64); oi[j] = __shfl_xor(bi[j], xm, 64); }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                double d2 = od[j];
+                long long id = oi[j];
+                if (!better(d2, id, bd[K - 1], bi[K - 1])) continue;   // (the partner's list is sorted: the rest is no better)
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    if (better(d2, id, bd[u], bi[u])) {
+                        const double td = bd[u]; const long long ti = bi[u];
+                        bd[u] = d2; bi[u] = id;
+                        d2 = td; id = ti;
+                    }
+                }
+            }
+        }
+        // ---- radius the staged box certainly covers: distance to its nearest face
+        if (open) {
+            const double cell = gv.cell0 * (double)(1ll << (2 * level));
+            const int bl = (int)(PCR_COORD_BIAS >> (2 * level));
+            const double a[3] = {ax, ay, az};
+            const int b0[3] = {x0, y0, z0};
+            double cover = DBL_MAX;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double f_lo = gv.lo[d] + (double)(b0[d] - bl) * cell, f_hi = gv.lo[d] + (double)(b1[d] + 1 - bl) * cell;
+                cover = fmin(cover, fmin(a[d] - f_lo, f_hi - a[d]));
+            }
+            cover = fmax(cover - cell * 1e-9, 0.0);
+            double kth = DBL_MAX;
+#pragma unroll
+            for (int j = 0; j < K; ++j) kth = (j == k - 1) ? bd[j] : kth;
+            if (kth <= cover * cover) {
+                proven = true;
+                open = false;
+                if (sub == 0) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        if (j < k) {
+                            idx_out[qi * k + j] = (int)bi[j];
+                            dist_out[qi * k + j] = sqrt(bd[j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const bool redo = valid && !proven && sub == 0;
+    const unsigned long long m = __ballot(redo);
+    if (m) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(redo_count, (unsigned int)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (redo) redo_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)qi;
+    }
+}
+
+// a fixed grid of waves strides over the tiles: their number is only known on the device (the list the first stage left), and one
+// block per four POSSIBLE tiles was 30 000 blocks that read the count and left (0.1 ms of a 0.5-ms call)
+template <int K, int LPQ, int PASSES, int ROUNDS>
+__global__ void __launch_bounds__(256)
+knn_tile_kernel(pcr_grid_view gv, const double* __restrict__ queries, const unsigned int* __restrict__ order, long long n_static, const unsigned int* __restrict__ count_p,
+                int k, int* __restrict__ idx_out, double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count) {
+    __shared__ knn_tile_lds s_lds[4];
+    constexpr int QPT = 64 / LPQ;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long nq = count_p ? (long long)*count_p : n_static;
+    const long long n_tiles = (nq + QPT - 1) / QPT;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+        knn_tile_one<K, LPQ, PASSES, ROUNDS>(gv, &s_lds[wave], lane, tile, nq, queries, order, k, idx_out, dist_out, redo_list, redo_count);
+        kt_wave_sync();
+    }
+}
+
 extern "C" {
 
 int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t q, int k, int32_t* idx_out, double* dist_out) {
@@ -353,23 +600,52 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
     double* d_dist = b_dist.as<double>();
     PCR_HIP(ctx, hipMemcpyAsync(b_q.p, queries, sizeof(double) * 3 * q, hipMemcpyHostToDevice, ctx->stream));
     static const bool no_block = getenv("PCR_KNN_NO_BLOCK") != nullptr;
+    static const bool no_tiles = getenv("PCR_KNN_NO_TILES") != nullptr;   // A/B: the lane-per-query kernel at every level, then the descent (round 2)
     if (k <= 16 && q >= 256 && !no_block) {
-        // batched path: lane-per-query block scan, then the wave-per-query descent for what it could not prove
-        unsigned int* d_redo_count = ctx->d_counters + 125;
-        if ((rc = b_redo.alloc(sizeof(int) * q))) return rc;
-        int* d_redo = b_redo.as<int>();
-        PCR_HIP(ctx, hipMemsetAsync(d_redo_count, 0, sizeof(unsigned int), ctx->stream));
+        // Batched path, three stages, each handing what it cannot prove to the next through a list:
+        //   1. the lane-per-query scan at the finest level(s) only -- a query's own 27 cells: where it is fast and proves the easy majority;
+        //   2. ONE QUERY PER WAVE for what it leaves: all 64 lanes scan the query's own box -- its cells and a ring, then the ball its
+        //      k-th distance so far defines, or rings of 4, 16, 64 ... cells while it lacks k points (knn_tile_kernel);
+        //   3. the lane-per-query scan at every level and the wave-per-query descent for what is left (clamped coordinates).
+        unsigned int* d_cnt_a = ctx->d_counters + 125;   // queries stage 2 left
+        unsigned int* d_cnt_b = ctx->d_counters + 126;   // queries the full block scan left (-> descent)
+        unsigned int* d_cnt_d = ctx->d_counters + 127;   // queries stage 1 left
+        pcr_dev_block b_redo2(ctx), b_redo4(ctx);
+        if ((rc = b_redo.alloc(sizeof(int) * q)) || (rc = b_redo2.alloc(sizeof(int) * q)) || (rc = b_redo4.alloc(sizeof(int) * q))) return rc;
+        int *d_redo_a = b_redo.as<int>(), *d_redo_b = b_redo2.as<int>(), *d_redo_d = b_redo4.as<int>();
+        PCR_HIP(ctx, hipMemsetAsync(d_cnt_a, 0, 3 * sizeof(unsigned int), ctx->stream));
         const unsigned gb = (unsigned)((q + 255) / 256);
+        if (!no_tiles) {
+            const int lv_first = k > 8 ? 1 : 0;   // (k = 16, a scan against itself: 44 000 of 120 000 queries are left at level 0)
+            unsigned gw = (unsigned)((q + 3) / 4);
+            if (gw > 8u * (unsigned)ctx->cu_count) gw = 8u * (unsigned)ctx->cu_count;   // (a fixed grid strides over the list: its length is only known on the device)
+            if (k <= 8) {
+                hipLaunchKernelGGL(knn_block_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_d, d_cnt_d,
+                                   (const int*)nullptr, (const unsigned int*)nullptr, lv_first);
+                hipLaunchKernelGGL((knn_tile_kernel<8, 64, 7, 512>), dim3(gw), dim3(256), 0, ctx->stream, index->view, d_q, (const unsigned int*)d_redo_d, (long long)q,
+                                   (const unsigned int*)d_cnt_d, k, d_idx, d_dist, d_redo_a, d_cnt_a);
+            } else {
+                hipLaunchKernelGGL(knn_block_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_d, d_cnt_d,
+                                   (const int*)nullptr, (const unsigned int*)nullptr, lv_first);
+                hipLaunchKernelGGL((knn_tile_kernel<16, 64, 7, 512>), dim3(gw), dim3(256), 0, ctx->stream, index->view, d_q, (const unsigned int*)d_redo_d, (long long)q,
+                                   (const unsigned int*)d_cnt_d, k, d_idx, d_dist, d_redo_a, d_cnt_a);
+            }
+        }
+        const int* todo = no_tiles ? nullptr : d_redo_a;
         if (k <= 8)
-            hipLaunchKernelGGL(knn_block_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo, d_redo_count);
+            hipLaunchKernelGGL(knn_block_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_b, d_cnt_b, todo,
+                               (const unsigned int*)d_cnt_a, PCR_KNN_LV);
         else
-            hipLaunchKernelGGL(knn_block_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo, d_redo_count);
-        unsigned int n_redo = 0;
-        PCR_HIP(ctx, hipMemcpyAsync(&n_redo, d_redo_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+            hipLaunchKernelGGL(knn_block_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_b, d_cnt_b, todo,
+                               (const unsigned int*)d_cnt_a, PCR_KNN_LV);
+        unsigned int n_redo[3] = {0, 0, 0};
+        PCR_HIP(ctx, hipMemcpyAsync(n_redo, d_cnt_a, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (n_redo)
-            hipLaunchKernelGGL(knn_kernel, dim3((n_redo + 3) / 4), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, (const int*)d_redo,
-                               (const unsigned int*)d_redo_count);
+        static const bool dbg = getenv("PCR_KNN_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "pcr_knn: %lld queries, k = %d: %u left by the first scan, %u by the wave-per-query boxes, %u to the descent\n", (long long)q, k, n_redo[2], n_redo[0], n_redo[1]);
+        if (n_redo[1])
+            hipLaunchKernelGGL(knn_kernel, dim3((n_redo[1] + 3) / 4), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, (const int*)d_redo_b,
+                               (const unsigned int*)d_cnt_b);
     } else {
         hipLaunchKernelGGL(knn_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, (const int*)nullptr,
                            (const unsigned int*)nullptr);
