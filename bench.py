@@ -201,7 +201,9 @@ def concurrent_leg(pkg, dev_id, src, tgt, n_pairs, steps):
 
 def filter_pairs_per_pass(pkg, dev_id, src, tgt, cell):
     """(query, staged candidate) pairs the tile kernel's filter evaluates in one pass over the bench pair: read from the
-    kernel's own per-tile stamps (PCR_DEBUG_STAMPS) on a throw-away context, untimed."""
+    kernel's own per-tile stamps (PCR_DEBUG_STAMPS) on a throw-away context, untimed.  The counters are a run-time switch of the
+    stand-alone tile kernel only (in the one-launch pass they are compiled in by -DPCR_PASS_DIAG=1), so this ICP runs the
+    tile -> hard -> accumulate launches (PCR_ICP_NO_FUSED): the same tile code on the same queries."""
     import ctypes as C
 
     os.environ["PCR_DEBUG_STAMPS"] = "1"
@@ -211,7 +213,11 @@ def filter_pairs_per_pass(pkg, dev_id, src, tgt, cell):
         del os.environ["PCR_DEBUG_STAMPS"]
     idx = pkg.TargetIndex(pkg.DeviceCloud.upload(tgt, c), cell=cell, ctx=c)
     sd = pkg.DeviceCloud.upload(src, c).prepare(idx)
-    pkg.icp_device(sd, idx, np.eye(4), mode="total", max_iter=2, r_thres=-1.0, t_thres=-1.0, max_d2=MAX_D2, min_iter=2)
+    os.environ["PCR_ICP_NO_FUSED"] = "1"
+    try:
+        pkg.icp_device(sd, idx, np.eye(4), mode="total", max_iter=2, r_thres=-1.0, t_thres=-1.0, max_d2=MAX_D2, min_iter=2)
+    finally:
+        del os.environ["PCR_ICP_NO_FUSED"]
     nb = (len(src) + 63) // 64
     buf = np.zeros(nb * 4, dtype=np.uint64)
     L = pkg._lib

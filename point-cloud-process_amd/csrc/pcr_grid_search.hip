@@ -188,17 +188,19 @@ __device__ static inline double wave_total_f64(double v) {
 
 // all-reduce inside every row of 16 lanes (= the 16 queries of a candidate slice): quad swaps, half mirror, mirror
 __device__ static inline int row16_min(int v) {
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror
+    // (old = 0 with bound_ctrl: every lane has a source under these permutations, and the compiler can then fold the move into the
+    // v_min / v_max -- with old = v it emitted v_mov + v_mov_dpp + v_min per step, 72 instructions for the six reductions of a tile)
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));  // row_mirror
     return v;
 }
 __device__ static inline int row16_max(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
     return v;
 }
 
@@ -209,6 +211,13 @@ __device__ static inline unsigned int wave_excl_scan_u32(unsigned int v, int lan
 }
 
 struct wt_xyz { double x, y, z; };  // the 24 coordinate bytes of a pcr_pt record
+
+// the 24 coordinate bytes of a record by GLOBAL loads: the grid view's pointers are generic, and copying a struct through an
+// address_space(1) pointer still comes out as flat loads (the aggregate copy drops the address space); three doubles do not
+__device__ static inline wt_xyz ld_xyz_global(const void* p) {
+    const __attribute__((address_space(1))) double* g = (const __attribute__((address_space(1))) double*)reinterpret_cast<const double*>(p);
+    return wt_xyz{g[0], g[1], g[2]};
+}
 
 // pointers read from the device copy of the grid view are generic; tell the compiler they are global memory
 template <typename T>
@@ -383,6 +392,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
         WT_STAMP(1);
         // ---- directory: one 2x2x2 block per lane (<= 64 blocks by the level choice)
         unsigned int ncell = 0;
+        bool big_child = false;
         {
             const int lim = (int)(PCR_COORD_MAX >> (2 * level));
             const int bx0 = blo0 >> 1, by0 = blo1 >> 1, bz0 = blo2 >> 1;
@@ -393,11 +403,12 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
             int BX = 0, BY = 0, BZ = 0;
             if (lane < nblk) {
                 // block index -> (ix, iy, iz) without an integer division (lane < 64: the float quotient is fixed up)
-                int iz = (int)((float)lane * (1.0f / (float)nb01));
+                // (v_rcp_f32: within 1 ulp, and the quotient is fixed up either way; a true division is a 12-instruction sequence)
+                int iz = (int)((float)lane * __builtin_amdgcn_rcpf((float)nb01));
                 iz -= (iz * nb01 > lane);
                 iz += ((iz + 1) * nb01 <= lane);
                 const int rem = lane - iz * nb01;
-                int iy = (int)((float)rem * (1.0f / (float)nb0));
+                int iy = (int)((float)rem * __builtin_amdgcn_rcpf((float)nb0));
                 iy -= (iy * nb0 > rem);
                 iy += ((iy + 1) * nb0 <= rem);
                 const int ix = rem - iy * nb0;
@@ -406,17 +417,15 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                 if (BX >= 0 && BY >= 0 && BZ >= 0 && BX <= blim && BY <= blim && BZ <= blim)
                     have = lookup_block(as_global(gv.btable[level]), gv.bmask[level], (unsigned int)BX, (unsigned int)BY, (unsigned int)BZ, &e);
             }
-            // occupied children inside the box -> compact cell list (start, count) in LDS, in slot order
+            // occupied children inside the box -> compact cell list (start, count) in LDS, in slot order.  A block with a child too
+            // large for its 16-bit count (> 65 535 points in one cell: duplicates) makes the tile give up below -- its queries go to
+            // the exact descent, which splits such cells 64 ways; asking the cell table here instead cost eight unrolled four-load
+            // probes of code and registers for a case no scan ever produces
+            big_child = __any(have && e.flags != 0);
             unsigned int run = have ? e.start : 0u;
 #pragma unroll
             for (int ch = 0; ch < 8; ++ch) {
-                unsigned int cs = run, cn = have ? (unsigned int)e.cnt[ch] : 0u;
-                if (have && e.flags) {  // a child too large for 16 bits: ask the cell table
-                    unsigned int s2 = 0, e2 = 0;
-                    lookup_cell(as_global(gv.table[level]), gv.mask[level], (unsigned int)(2 * BX + (ch & 1)), (unsigned int)(2 * BY + ((ch >> 1) & 1)),
-                                (unsigned int)(2 * BZ + (ch >> 2)), &s2, &e2);
-                    cs = s2; cn = e2 - s2;
-                }
+                const unsigned int cs = run, cn = have ? (unsigned int)e.cnt[ch] : 0u;
                 run += cn;
                 const int X = 2 * BX + (ch & 1) - blo0, Y = 2 * BY + ((ch >> 1) & 1) - blo1, Z = 2 * BZ + (ch >> 2) - blo2;
                 const bool in = have && cn > 0 && X >= 0 && Y >= 0 && Z >= 0 && X < d0 && Y < d1 && Z < d2;
@@ -445,6 +454,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
             if (c < ncell) L->c_off[c] = total + pre;
             total += t;
         }
+        if (big_child) total = pcap + 1u;   // (more than the cap: the tile gives up)
         wave_sync();
         WT_STAMP(3);
         staged += total;
@@ -478,36 +488,47 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
             const int slice = lane / WT_Q;
 #endif
             unsigned int carry = 0;  // owner cell of the last position of the previous round
-#pragma unroll 1
-            for (unsigned int base = 0; base < total; base += WT_PR) {
-                const unsigned int cnt = min(total - base, (unsigned int)WT_PR);
-                // owner cell of every staged position: mark the first position of each cell (slot ids increase with the
-                // position, cells are non-empty), then a running maximum over the positions
+            // Addresses and loads of one round (positions [b, b + n) of the box): owner cell of every staged position -- mark the
+            // first position of each cell (slot ids increase with the position, cells are non-empty), then a running maximum over
+            // the positions -- and the (up to) three target records of this lane, requested back to back: one memory round trip.
+            // (Every element of R is assigned on every path: left conditionally unassigned, the nine doubles became loop-carried
+            // values -- 18 registers alive through the filter and the directory: 102 -> 87 VGPRs for the stand-alone tile kernel.)
+            auto request = [&](const unsigned int b, const unsigned int n, unsigned int (&J)[WT_CH], wt_xyz (&R)[WT_CH]) {
 #pragma unroll
                 for (int c3 = 0; c3 < WT_CH; ++c3) L->own[64 * c3 + lane] = 0;
                 wave_sync();
                 for (unsigned int c = lane; c < ncell; c += 64) {
                     const unsigned int f = L->c_off[c];
-                    if (f >= base && f < base + cnt) L->own[f - base] = (unsigned short)c;
+                    if (f >= b && f < b + n) L->own[f - b] = (unsigned short)c;
                 }
                 wave_sync();
                 unsigned int ow[WT_CH];
 #pragma unroll
                 for (int c3 = 0; c3 < WT_CH; ++c3) ow[c3] = (unsigned int)L->own[64 * c3 + lane];
-                unsigned int jj[WT_CH];
 #pragma unroll
                 for (int c3 = 0; c3 < WT_CH; ++c3) {
                     unsigned int v = max(wave_incl_scan_max(ow[c3]), carry);
                     carry = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
                     const unsigned int k = 64 * c3 + lane;
-                    const unsigned int vv = k < cnt ? v : 0u;
-                    jj[c3] = L->c_start[vv] + (base + k - L->c_off[vv]);
+                    const unsigned int vv = k < n ? v : 0u;
+                    J[c3] = L->c_start[vv] + (b + k - L->c_off[vv]);
                 }
-                // the (up to) three target records of this lane, requested back to back: one memory round trip per round
-                wt_xyz rec[WT_CH];
 #pragma unroll
-                for (int c3 = 0; c3 < WT_CH; ++c3)
-                    if (64 * c3 + lane < cnt) rec[c3] = *reinterpret_cast<const wt_xyz*>(&g_pts[jj[c3]]);
+                for (int c3 = 0; c3 < WT_CH; ++c3) {
+                    R[c3] = wt_xyz{0.0, 0.0, 0.0};
+                    // (a GLOBAL load, spelled out: a flat load also counts on the LDS counter -- every LDS wait of the filter would wait
+                    // for the records in flight)
+                    if (64 * c3 + lane < n) R[c3] = ld_xyz_global(&g_pts[J[c3]]);
+                }
+            };
+            // The rounds are software-pipelined: the records of round r + 1 are requested BEFORE the filter of round r runs, so a tile
+            // of several rounds -- the launch's last finishers -- pays one gather round trip, not one per round.
+            unsigned int jj[WT_CH];
+            wt_xyz rec[WT_CH];
+            request(0u, min(total, (unsigned int)WT_PR), jj, rec);
+#pragma unroll 1
+            for (unsigned int base = 0; base < total; base += WT_PR) {
+                const unsigned int cnt = min(total - base, (unsigned int)WT_PR);
 #pragma unroll
                 for (int c3 = 0; c3 < WT_CH; ++c3) {
                     const unsigned int k = 64 * c3 + lane;
@@ -527,6 +548,11 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                 if (lane < 8) { L->px[cnt + lane] = 1e30f; L->py[cnt + lane] = 0.0f; L->pz[cnt + lane] = 0.0f; }  // pad the last group of 8
 #endif
                 wave_sync();
+                unsigned int jn[WT_CH];
+                wt_xyz rn[WT_CH];
+#pragma unroll
+                for (int c3 = 0; c3 < WT_CH; ++c3) { jn[c3] = 0u; rn[c3] = wt_xyz{0.0, 0.0, 0.0}; }
+                if (base + WT_PR < total) request(base + WT_PR, min(total - base - WT_PR, (unsigned int)WT_PR), jn, rn);   // in flight during the filter
                 WT_STAMP(4);
 #if PCR_WT_MFMA
                 // Filter on the matrix cores.  Expanded form |p|^2 - 2 q.p (the query's own |q|^2 is added at the end): one 32 x 32
@@ -638,6 +664,8 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                 }
 #endif
                 wave_sync();
+#pragma unroll
+                for (int c3 = 0; c3 < WT_CH; ++c3) { jj[c3] = jn[c3]; rec[c3] = rn[c3]; }
                 WT_STAMP(5);
             }
 #if PCR_WT_MFMA
@@ -725,8 +753,10 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
             const unsigned int n_r = (unsigned int)__popcll(__ballot(unres && (clamped ? 0 : why) == r));
             if (lane == 0 && n_r) atomicAdd(&dbg[(1 << 15) + r], (unsigned long long)n_r);
         }
-        if (lane == 0 && (threadIdx.x >> 6) == 0)
-            for (int i = 0; i < 8; ++i) dbg[(1 << 16) + blockIdx.x * 8 + i] = t_ph[i];
+        if (lane == 0) {   // every wave's phases; slot 7 = points staged by the tile
+            t_ph[7] = staged;
+            for (int i = 0; i < 8; ++i) dbg[(1 << 16) + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i] = t_ph[i];
+        }
     }
 #endif
 }
@@ -1298,11 +1328,19 @@ __device__ __forceinline__ static void pass_finish(const pcr_grid_view& gv, pass
     if (dbg && lane == 0) dbg[(1 << 19) - 1] = __builtin_amdgcn_s_memrealtime();
 }
 
+#ifndef PCR_PASS_DIAG
+#define PCR_PASS_DIAG 0
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
 grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, double max_d2, int xcd_remap,
-                 unsigned int pcap, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg, int use_prev, int inline_queue, pass_args A) {
+                 unsigned int pcap, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg_arg, int use_prev, int inline_queue, pass_args A) {
+    // the kernel's own stamps and counters (scripts/pass_stamps.py, wt_stamps.py, hard_stamps.py) are compiled in by -DPCR_PASS_DIAG=1 only:
+    // as a run-time switch they kept ~14 scalar registers alive through the whole kernel, which spills scalars into vector lanes as it is
+    unsigned long long* const dbg = PCR_PASS_DIAG ? dbg_arg : nullptr;
     __shared__ pass_lds s_lds[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index is the same in every lane: through readfirstlane everything derived from it -- the tile, its queue group, half a
+    // dozen pointers -- lives in scalar registers instead of occupying a vector register pair each)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned int tile = wtile_block(xcd_remap) * 4 + wave;
     // the tile's records and the loop state are requested together; a pass enqueued behind a stop leaves before any side effect
     wt_pre P;
@@ -2210,7 +2248,9 @@ __device__ static inline const pcr_batch_pair* batch_pair_ptr(const pcr_batch_pa
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
 batch_pass_kernel(pcr_batch_pass_args B, int xcd_remap, unsigned int pcap, unsigned int pass_id, int use_prev) {
     __shared__ pass_lds s_lds[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index is the same in every lane: through readfirstlane everything derived from it -- the tile, its queue group, half a
+    // dozen pointers -- lives in scalar registers instead of occupying a vector register pair each)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned int tile_g = (unsigned int)__builtin_amdgcn_readfirstlane((int)(wtile_block(xcd_remap) * 4 + wave));
     const unsigned int p = (unsigned int)__builtin_amdgcn_readfirstlane((int)as_global(B.tile_pair)[tile_g]);
     if (p >= (unsigned int)B.n_pairs) return;   // (slot of a pair that was rejected on the host)

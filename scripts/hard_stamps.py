@@ -1,3 +1,6 @@
+"""Per-item stamps of the exact descent (queue items of the one-launch ICP pass / the stand-alone hard stage).
+For the one-launch pass build scripts/build_variant.sh pdiag "-DPCR_PASS_DIAG=1" and run with
+PCR_LIB_PATH=scripts/bin/libpcr_pdiag.so: the product build compiles the pass kernel's stamps out."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 os.environ["PCR_DEBUG_STAMPS"] = "1"

@@ -1,5 +1,6 @@
 """Per-wave timeline of the one-kernel ICP pass (PCR_DEBUG_STAMPS=1): when a wave's tile ended, when its moments were in,
-when it left the work queue, how many items it served, polls and lost compare-and-swaps; 100-MHz real-time stamps."""
+when it left the work queue, how many items it served, polls and lost compare-and-swaps; 100-MHz real-time stamps.
+Needs scripts/build_variant.sh pdiag "-DPCR_PASS_DIAG=1" and PCR_LIB_PATH=scripts/bin/libpcr_pdiag.so: the product build compiles the stamps out."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 os.environ["PCR_DEBUG_STAMPS"] = "1"
