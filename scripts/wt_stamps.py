@@ -36,3 +36,7 @@ for lo, hi in ((0, 65), (65, 129), (129, 193), (193, 385), (385, 577), (577, 769
     sel = (staged >= lo) & (staged < hi)
     if sel.any():
         print("   [%4d, %6d): %5d | %s | %.0f" % (lo, hi, sel.sum(), " ".join("%s %.0f" % (nm.split("+")[0][:6], np.median(ph[sel, i])) for i, nm in enumerate(names[:7])), np.median(ph[sel].sum(axis=1))))
+tot = ph.sum(axis=1)
+print("slowest 16 tiles (total | staged | phases):")
+for k in np.argsort(-tot)[:16]:
+    print("   %6.0f | %4d | %s" % (tot[k], staged[k], " ".join("%s %.0f" % (nm.split("+")[0][:6], ph[k, i]) for i, nm in enumerate(names[:7]))))
