@@ -121,6 +121,10 @@ constexpr int WT_PASSES = PCR_WT_PASSES;
 #define PCR_WT_PASSES_SEEDED 1
 #endif
 constexpr int WT_PASSES_SEEDED = WT_PASSES < PCR_WT_PASSES_SEEDED ? WT_PASSES : PCR_WT_PASSES_SEEDED;
+#ifndef PCR_WT_HEAVY_STOP
+#define PCR_WT_HEAVY_STOP 384   // (192: 78.8-81.2, 384: 77.6-79.0, 576: 79.8-80.0 us for a one-iteration registration of the 120k pair; without: 81.4-82.0)
+#endif
+constexpr int WT_HEAVY_STOP = PCR_WT_HEAVY_STOP;
 constexpr int WT_ROUNDS_SMALL = 768 / WT_PR, WT_ROUNDS_LARGE = 2304 / WT_PR;   // staged-point caps of 768 / 2304 per tile
 
 #ifndef PCR_WT_MFMA
@@ -336,14 +340,20 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
     unsigned int dbg_passes = 0, staged = 0;
     // seeded tiles (ICP passes after the first) settle 97 % of their queries in pass 0; a third pass only feeds the kernel's tail
     const int max_passes = prev_xyz ? WT_PASSES_SEEDED : WT_PASSES;
+    unsigned int staged_done = 0;   // points actually staged so far (wave-uniform)
+    float ring = 1.0f;   // half-width, in level-0 cells, of the cube a query without a candidate claims (wave-uniform)
 #pragma unroll 1
     for (int pass = 0; pass < max_passes; ++pass) {
         const bool part = open && !clamped;
         if (!__any(part)) break;
+        // unseeded passes: a tile that has already staged a lot leaves what is still open to the queue instead of staging another
+        // box -- the first pass of an ICP ends with its slowest (three-pass) tiles, and since dense tiles retry with their own cells
+        // (below) the queue has the room: slowest tile 39.6 -> 31.0 us, 4 366 -> 4 998 items, one-iteration registration 82 -> 78.5 us
+        if (pass > 0 && staged_done > (unsigned int)WT_HEAVY_STOP) break;
         // ---- the cube every open query claims, in level-0 cell coordinates
         int mn[3], mx[3];
         {
-            const float rho = (cand_pos != POS_NONE) ? sqrtf(bound2) * (1.0f + 1e-6f) : fminf((float)gv.cell0 * (float)(1 << (2 * pass)), sqrtf(gate2));
+            const float rho = (cand_pos != POS_NONE) ? sqrtf(bound2) * (1.0f + 1e-6f) : fminf((float)gv.cell0 * ring, sqrtf(gate2));
             // half-width in cells; the claim only steers the box (what is proven is decided against the box actually staged)
             const double rc = fmin((double)rho * gv.inv_cell0, 262144.0);
             // the query in level-0 cell units (clamped queries never take part)
@@ -465,7 +475,18 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
             else if (staged > 2 * WT_PR) __builtin_amdgcn_s_setprio(2);
             else if (staged > WT_PR) __builtin_amdgcn_s_setprio(1);
         }
-        if (total > pcap) { if (part) WT_WHY(2); continue; }   // too many points to stage around this tile: a later pass has tighter balls, or the hard stage takes over
+        if (total > pcap) {
+            // Too many points to stage around this tile.  Unseeded passes: "cells + one ring" around 32 queries in a dense part of the
+            // scan (the first pass of an ICP left 329 of 3 752 tiles like that, 9 109 of its 9 116 queue items, and every further pass
+            // of such a tile claimed MORE) -- the next pass claims the queries' own cells only: almost every query finds a candidate
+            // centimetres away there, and the pass after that stages the tight balls.  If even that is too much, the tile stops
+            // at once and the queue takes over (seeded passes: their claims are tight balls already).
+            if (part) WT_WHY(2);
+            if (prev_xyz || ring == 0.0f) break;
+            ring = 0.0f;
+            continue;
+        }
+        staged_done += total;
         if (dbg) dbg_pairs += (unsigned long long)total * (unsigned long long)__popcll(__ballot(part && lane < WT_Q));
         const float cellLf = (float)gv.cell0 * (float)(1 << (2 * level));
         const double cellL = gv.cell0 * (double)(1ll << (2 * level));
@@ -732,6 +753,7 @@ __device__ __forceinline__ static void wtile_search(const pcr_grid_view& gv, wti
                 }
             }
         }
+        ring = ring == 0.0f ? 1.0f : ring * 4.0f;   // queries still without a candidate claim a wider cube next
     }
     WT_STAMP(6);
     S.ax = ax; S.ay = ay; S.az = az;
