@@ -9,6 +9,7 @@
 namespace pcr {
 
 __host__ __device__ inline void T_from_xform(const pcr_xform& x, double T[16]) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) T[4 * i + j] = x.r[3 * i + j];
         T[4 * i + 3] = x.t[i];
@@ -17,7 +18,8 @@ __host__ __device__ inline void T_from_xform(const pcr_xform& x, double T[16]) {
     T[15] = 1.0;
 }
 
-__host__ __device__ inline void T_mul4(const double A[16], const double B[16], double C[16]) {  // C may alias A or B
+__host__ __device__ inline void T_mul4(const double A[16], const double B[16], double C[16]) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h  // C may alias A or B
     double r[16];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
@@ -33,6 +35,7 @@ __host__ __device__ inline void T_mul4(const double A[16], const double B[16], d
 constexpr size_t ICP_STATE_HEAD_BYTES = offsetof(pcr_icp_dev_state, r_diff);
 __host__ __device__ inline void icp_step(pcr_icp_dev_state* st, const double* m, const double origin[3], const pcr_icp_loop_args& la,
                                          double* r_log, double* t_log) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
     double T_cur[16];
     T_from_xform(st->x, T_cur);
     T_mul4(T_cur, st->T_total, st->T_total);

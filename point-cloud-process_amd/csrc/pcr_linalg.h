@@ -1,4 +1,9 @@
 // 3x3 linear algebra for the Procrustes step (binary64), usable from host code and from kernels.
+// The library is built with -ffp-contract=off (the searches' proofs count roundings); the functions of this header and of
+// pcr_icp_step.h opt back in (#pragma clang fp contract(fast)): on the device the step is ONE lane's chain of ~1 000 dependent
+// binary64 operations at the end of every ICP pass, a quarter of them multiply-add pairs -- fused they shorten the pass by 0.7 us
+// of 37 (same-box A/B).  Every device kernel compiles the same expressions the same way (the fused batch stays bitwise equal
+// to the per-pair path: tested), and nothing here is compared bitwise with the host build of the same functions (goldens: 1e-9).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -13,6 +18,7 @@ namespace pcr {
 // and the convergence tests compare squares instead of dividing.
 template <int P, int Q>
 __host__ __device__ inline void svd3_rotate(double A[9], double V[9], bool& rotated) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
     const double alpha = (A[P] * A[P] + A[3 + P] * A[3 + P]) + A[6 + P] * A[6 + P];
     const double beta = (A[Q] * A[Q] + A[3 + Q] * A[3 + Q]) + A[6 + Q] * A[6 + Q];
     const double gamma = (A[P] * A[Q] + A[3 + P] * A[3 + Q]) + A[6 + P] * A[6 + Q];
@@ -59,6 +65,7 @@ __host__ __device__ inline void svd3_rotate(double A[9], double V[9], bool& rota
 // column B of U := cross product of the other two columns
 template <int B>
 __host__ __device__ inline void svd3_complete_one(double U[9]) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
     constexpr int p = (B + 1) % 3, q = (B + 2) % 3;
     const double c0 = U[3 * 1 + p] * U[3 * 2 + q] - U[3 * 2 + p] * U[3 * 1 + q];
     const double c1 = U[3 * 2 + p] * U[3 * 0 + q] - U[3 * 0 + p] * U[3 * 2 + q];
@@ -69,6 +76,7 @@ __host__ __device__ inline void svd3_complete_one(double U[9]) {
 // rank <= 1: column G is the only usable one (or none is: have == false): build any orthonormal completion
 template <int G>
 __host__ __device__ inline void svd3_complete_two(double U[9], bool have) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
     double u0[3] = {1, 0, 0};
     if (have) { u0[0] = U[G]; u0[1] = U[3 + G]; u0[2] = U[6 + G]; }
     const int ax = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
@@ -88,6 +96,7 @@ __host__ __device__ inline void svd3_complete_two(double U[9], bool have) {
 // then start from A = H V0, which is already close to orthogonal columns, and usually one or two sweeps remain.
 // Any orthogonal V0 yields a valid decomposition; R = U V^T does not depend on it beyond rounding.
 __host__ __device__ inline void svd3(const double H[9], double U[9], double s[3], double V[9], const double* V0 = nullptr) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
     double A[9];
     if (V0) {
         for (int i = 0; i < 9; ++i) V[i] = V0[i];
@@ -136,6 +145,7 @@ __host__ __device__ inline void svd3(const double H[9], double U[9], double s[3]
 }
 
 __host__ __device__ inline void mat3_mul(const double A[9], const double B[9], double C[9]) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
@@ -146,6 +156,7 @@ __host__ __device__ inline void mat3_mul(const double A[9], const double B[9], d
 // t = bbar - R abar, cost = ||B - (R A + t)||_F (main.py:140-141).
 __host__ __device__ inline void kabsch_from_moments(const double m[18], const double origin[3], double R[9], double t[3], double* cost,
                                                     double* V_io = nullptr) {
+#pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
     const double K = m[0], invK = 1.0 / K;
     double abar[3] = {m[1] * invK, m[2] * invK, m[3] * invK};
     double bbar[3] = {m[4] * invK, m[5] * invK, m[6] * invK};
