@@ -138,7 +138,8 @@ def run_icp_steps(pkg, index, src_host, steps, ctx, sd=None):
     """Exactly `steps` ICP iterations (thresholds off), device-resident inputs.  `sd`: a source cloud already uploaded
     and laid out (the timed run hands one in so that the set-up stays outside the timed region).  Returns dict."""
     out = {"iters": 0, "device_ms": 0.0, "nn_kernel_ms": 0.0, "nn_launches": 0}
-    if sd is None:
+    own_sd = sd is None
+    if own_sd:
         sd = pkg.DeviceCloud.upload(src_host, ctx).prepare(index)  # resident + laid out before the timed region
     T0 = np.eye(4)
     ctx.sync()
@@ -157,7 +158,8 @@ def run_icp_steps(pkg, index, src_host, steps, ctx, sd=None):
     out["wall_s"] = time.perf_counter() - t0
     out["n_assoc"] = last["n_assoc"]
     out["T_total"] = last["T_total"]
-    sd.free()
+    if own_sd:
+        sd.free()   # (a cloud handed in is the caller's to release -- after its timed region: releasing device memory is not a step)
     return out
 
 
@@ -526,6 +528,7 @@ def main():
         dist.all_gather(allrec, rec)
     barrier()
     elapsed = time.perf_counter() - t0
+    sd_timed.free()
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
