@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <chrono>
 #include <thread>
+#include <atomic>
+#include <memory>
 #include "pcr_internal.h"
 
 extern "C" {
@@ -171,24 +173,42 @@ int pcr_d2h_staged(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t byt
     const size_t n_chunks = (bytes + half - 1) / half;
     char* const pin = (char*)ctx->h_down;
     auto chunk_bytes = [&](size_t c) { return c + 1 < n_chunks ? half : bytes - c * half; };
-    PCR_HIP(ctx, hipMemcpyAsync(pin, dev_src, chunk_bytes(0), hipMemcpyDeviceToHost, ctx->stream));
-    for (size_t c = 0; c < n_chunks; ++c) {
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // chunk c is in its half
-        if (c + 1 < n_chunks)
-            PCR_HIP(ctx, hipMemcpyAsync(pin + ((c + 1) & 1) * half, (const char*)dev_src + (c + 1) * half, chunk_bytes(c + 1), hipMemcpyDeviceToHost, ctx->stream));
-        {   // the host copy is the slower half of the pipeline (~10 GB/s on one core against ~25 GB/s of DMA): four threads per chunk
-            const size_t nb = chunk_bytes(c), quarter = (nb / 4 + 63) & ~(size_t)63;
-            char* const dst = (char*)host_dst + c * half;
-            const char* const src = pin + (c & 1) * half;
-            std::thread th[3];
-            for (int t = 0; t < 3; ++t) {
-                const size_t o = quarter * (size_t)(t + 1), len = o >= nb ? 0 : (o + quarter > nb || t == 2 ? nb - o : quarter);
-                th[t] = std::thread([=] { if (len) memcpy(dst + o, src + o, len); });
+    // The host copy out of the pinned halves is the slower side of the pipeline (~10 GB/s per core against ~55 GB/s of DMA): W
+    // persistent workers each copy their slice of every chunk as soon as the chunk has landed, and a half goes back to the DMA
+    // when all W slices of the chunk it held are out.  (Three threads started per chunk, as before, left the DMA waiting.)
+    constexpr int W = 8;
+    std::atomic<size_t> landed{0};   // chunks whose DMA has completed
+    std::atomic<int> failed{0};
+    std::unique_ptr<std::atomic<int>[]> outs(new std::atomic<int>[n_chunks]);
+    for (size_t c = 0; c < n_chunks; ++c) outs[c].store(0, std::memory_order_relaxed);
+    auto worker = [&](int w) {
+        for (size_t c = 0; c < n_chunks; ++c) {
+            while (landed.load(std::memory_order_acquire) <= c) {
+                if (failed.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
             }
-            memcpy(dst, src, quarter < nb ? quarter : nb);
-            for (int t = 0; t < 3; ++t) th[t].join();
+            const size_t nb = chunk_bytes(c), per = ((nb + W - 1) / W + 63) & ~(size_t)63;
+            const size_t o = per * (size_t)w, len = o >= nb ? 0 : (o + per > nb ? nb - o : per);
+            if (len) memcpy((char*)host_dst + c * half + o, pin + (c & 1) * half + o, len);
+            outs[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::thread th[W];
+    for (int w = 0; w < W; ++w) th[w] = std::thread(worker, w);
+    hipError_t e = hipMemcpyAsync(pin, dev_src, chunk_bytes(0), hipMemcpyDeviceToHost, ctx->stream);
+    for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+        e = hipStreamSynchronize(ctx->stream);   // chunk c is in its half
+        if (e != hipSuccess) break;
+        landed.store(c + 1, std::memory_order_release);
+        if (c + 1 < n_chunks) {
+            if (c >= 1)   // the other half held chunk c - 1
+                while (outs[c - 1].load(std::memory_order_acquire) < W) std::this_thread::yield();
+            e = hipMemcpyAsync(pin + ((c + 1) & 1) * half, (const char*)dev_src + (c + 1) * half, chunk_bytes(c + 1), hipMemcpyDeviceToHost, ctx->stream);
         }
     }
+    if (e != hipSuccess) failed.store(1, std::memory_order_relaxed);
+    for (int w = 0; w < W; ++w) th[w].join();
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
     return PCR_OK;
 }
 

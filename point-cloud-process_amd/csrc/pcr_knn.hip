@@ -682,6 +682,9 @@ int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries, int6
     }
     const int64_t total = offsets[q];
     if (total < 0) return PCR_E_INVALID;
+    const bool rt_on = getenv("PCR_RADIUS_TIMING") != nullptr;
+    auto rt_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double rt[6] = {rt_now(), 0, 0, 0, 0, 0};
     // the segmented sorts below index with 32 bits: more than 2^32 - 1 neighbours in one call (it fits in 288 GB) is refused
     // rather than silently truncated
     if (total > 0xffffffffll) { ctx->last_error = "pcr_radius: more than 2^32 - 1 neighbours in one call; split the queries"; return PCR_E_UNSUPPORTED; }
@@ -705,8 +708,11 @@ int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries, int6
         if ((rc = d_tmp.alloc(tb > 0 ? tb : 16))) return rc;
         PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(d_tmp.p, tb1, i1, i2, x1, x2, (unsigned int)total, (unsigned int)q, offs, offs + 1, 0, 32, ctx->stream));
         PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(d_tmp.p, tb2, x2, x1, i2, i1, (unsigned int)total, (unsigned int)q, offs, offs + 1, 0, 64, ctx->stream));
+        if (rt_on) { hipStreamSynchronize(ctx->stream); rt[1] = rt_now(); }
         if ((rc = pcr_d2h_staged(ctx, idx_out, i1, sizeof(int) * (size_t)total))) return rc;
+        if (rt_on) rt[2] = rt_now();
         if ((rc = pcr_d2h_staged(ctx, dist_out, x1, sizeof(double) * (size_t)total))) return rc;
+        if (rt_on) { rt[3] = rt_now(); fprintf(stderr, "pcr_radius: kernels + sorts %.2f ms, indices out %.2f ms (%.1f MB), distances out %.2f ms (%.1f MB)\n", rt[1] - rt[0], rt[2] - rt[1], 4e-6 * total, rt[3] - rt[2], 8e-6 * total); }
     }
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCR_OK;
