@@ -902,7 +902,13 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
                 S.finished.store(1, std::memory_order_release);
             }
         };
-        int n_workers = n_ctx;
+        // Packing (6-float records -> packed coordinates in the mapped staging block: 0.75 ms per sub-batch of 64 pairs on eight
+        // threads) is the critical path of a compat-mode batch -- every sub-batch's key kernel waits for it --, and the thread that
+        // launches a sub-batch leaves the pool until that sub-batch is done.  Threads are not tied to contexts: more of them pack.
+        const char* thr_s = getenv("PCR_BATCH_THREADS");
+        int n_workers = thr_s ? atoi(thr_s) : n_ctx;
+        if (n_workers < 1) n_workers = 1;
+        if (n_workers > 64) n_workers = 64;
         if ((int64_t)n_workers > n_tasks) n_workers = (int)n_tasks;
         if (n_workers <= 1) worker();
         else {
