@@ -62,34 +62,44 @@ __host__ __device__ inline void svd3_rotate(double A[9], double V[9], bool& rota
     }
 }
 
-// column B of U := cross product of the other two columns
-template <int B>
-__host__ __device__ inline void svd3_complete_one(double U[9]) {
+// Completion of U for (numerically) zero singular values.  Written with constant array indices and run-time SELECTS only: as three
+// template instantiations behind an if / else chain the compiler merged their stores into one tail with a variable index, U went to
+// scratch memory (64 bytes per lane), and a kernel that uses scratch pays for it at its first dispatch after kernels that do not:
+// 20 % of the waves of an ICP call's first pass started 6-8 us late (the whole chip waits for the scratch set-up of one rare branch).
+// column `bad` of U := cross product of the other two columns
+__host__ __device__ inline void svd3_complete_one(double U[9], const int bad) {
 #pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
-    constexpr int p = (B + 1) % 3, q = (B + 2) % 3;
-    const double c0 = U[3 * 1 + p] * U[3 * 2 + q] - U[3 * 2 + p] * U[3 * 1 + q];
-    const double c1 = U[3 * 2 + p] * U[3 * 0 + q] - U[3 * 0 + p] * U[3 * 2 + q];
-    const double c2 = U[3 * 0 + p] * U[3 * 1 + q] - U[3 * 1 + p] * U[3 * 0 + q];
-    U[B] = c0; U[3 + B] = c1; U[6 + B] = c2;
+    // p, q = the other two columns in cyclic order: bad = 0 -> (1, 2), 1 -> (2, 0), 2 -> (0, 1)
+    // (all nine elements are read into scalars FIRST: "b ? U[1] : U[2]" written on the array becomes ONE load with a selected address)
+    const double u0 = U[0], u1 = U[1], u2 = U[2], u3 = U[3], u4 = U[4], u5 = U[5], u6 = U[6], u7 = U[7], u8 = U[8];
+    const bool b0 = bad == 0, b1 = bad == 1, b2 = bad == 2;
+    const double p0 = b0 ? u1 : (b1 ? u2 : u0), p1 = b0 ? u4 : (b1 ? u5 : u3), p2 = b0 ? u7 : (b1 ? u8 : u6);
+    const double q0 = b0 ? u2 : (b1 ? u0 : u1), q1 = b0 ? u5 : (b1 ? u3 : u4), q2 = b0 ? u8 : (b1 ? u6 : u7);
+    const double c0 = p1 * q2 - p2 * q1, c1 = p2 * q0 - p0 * q2, c2 = p0 * q1 - p1 * q0;
+    U[0] = b0 ? c0 : u0; U[1] = b1 ? c0 : u1; U[2] = b2 ? c0 : u2;
+    U[3] = b0 ? c1 : u3; U[4] = b1 ? c1 : u4; U[5] = b2 ? c1 : u5;
+    U[6] = b0 ? c2 : u6; U[7] = b1 ? c2 : u7; U[8] = b2 ? c2 : u8;
 }
 
-// rank <= 1: column G is the only usable one (or none is: have == false): build any orthonormal completion
-template <int G>
-__host__ __device__ inline void svd3_complete_two(double U[9], bool have) {
+// rank <= 1: column `good` is the only usable one (or none is: have == false): build any orthonormal completion
+__host__ __device__ inline void svd3_complete_two(double U[9], const int good, const bool have) {
 #pragma clang fp contract(fast)   // see the note at the top of pcr_linalg.h
-    double u0[3] = {1, 0, 0};
-    if (have) { u0[0] = U[G]; u0[1] = U[3 + G]; u0[2] = U[6 + G]; }
-    const int ax = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+    const double u0 = U[0], u1 = U[1], u2 = U[2], u3 = U[3], u4 = U[4], u5 = U[5], u6 = U[6], u7 = U[7], u8 = U[8];
+    const bool g0 = good == 0, g1 = good == 1, g2 = good == 2;
+    const double a0 = have ? (g0 ? u0 : (g1 ? u1 : u2)) : 1.0;
+    const double a1 = have ? (g0 ? u3 : (g1 ? u4 : u5)) : 0.0;
+    const double a2 = have ? (g0 ? u6 : (g1 ? u7 : u8)) : 0.0;
+    const int ax = (fabs(a0) <= fabs(a1) && fabs(a0) <= fabs(a2)) ? 0 : (fabs(a1) <= fabs(a2) ? 1 : 2);
     const double e0 = ax == 0 ? 1.0 : 0.0, e1 = ax == 1 ? 1.0 : 0.0, e2 = ax == 2 ? 1.0 : 0.0;
-    double v1[3] = {u0[1] * e2 - u0[2] * e1, u0[2] * e0 - u0[0] * e2, u0[0] * e1 - u0[1] * e0};
-    const double n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
-    v1[0] /= n1; v1[1] /= n1; v1[2] /= n1;
-    const double v2[3] = {u0[1] * v1[2] - u0[2] * v1[1], u0[2] * v1[0] - u0[0] * v1[2], u0[0] * v1[1] - u0[1] * v1[0]};
-    // columns in the order G, then the remaining two ascending
-    constexpr int c1 = G == 0 ? 1 : 0, c2 = G == 2 ? 1 : 2;
-    U[G] = u0[0]; U[3 + G] = u0[1]; U[6 + G] = u0[2];
-    U[c1] = v1[0]; U[3 + c1] = v1[1]; U[6 + c1] = v1[2];
-    U[c2] = v2[0]; U[3 + c2] = v2[1]; U[6 + c2] = v2[2];
+    double v10 = a1 * e2 - a2 * e1, v11 = a2 * e0 - a0 * e2, v12 = a0 * e1 - a1 * e0;
+    const double n1 = sqrt(v10 * v10 + v11 * v11 + v12 * v12);
+    v10 /= n1; v11 /= n1; v12 /= n1;
+    const double v20 = a1 * v12 - a2 * v11, v21 = a2 * v10 - a0 * v12, v22 = a0 * v11 - a1 * v10;
+    // columns in the order `good`, then the remaining two ascending: the first remaining column is 1 if good == 0, else 0
+    const bool f0 = !g0, f1 = g0;   // column 0 / column 1 is the FIRST remaining column
+    U[0] = g0 ? a0 : (f0 ? v10 : v20); U[1] = g1 ? a0 : (f1 ? v10 : v20); U[2] = g2 ? a0 : v20;
+    U[3] = g0 ? a1 : (f0 ? v11 : v21); U[4] = g1 ? a1 : (f1 ? v11 : v21); U[5] = g2 ? a1 : v21;
+    U[6] = g0 ? a2 : (f0 ? v12 : v22); U[7] = g1 ? a2 : (f1 ? v12 : v22); U[8] = g2 ? a2 : v22;
 }
 
 // V0 (optional): an orthogonal starting basis, e.g. the V of a nearby matrix (consecutive ICP iterations): the sweeps
@@ -133,15 +143,8 @@ __host__ __device__ inline void svd3(const double H[9], double U[9], double s[3]
     }
     // complete U for (numerically) zero singular values (constant indices only: see svd3_rotate)
     const int nbad = (!ok[0]) + (!ok[1]) + (!ok[2]);
-    if (nbad == 1) {
-        if (!ok[0]) svd3_complete_one<0>(U);
-        else if (!ok[1]) svd3_complete_one<1>(U);
-        else svd3_complete_one<2>(U);
-    } else if (nbad >= 2) {
-        if (ok[2]) svd3_complete_two<2>(U, true);
-        else if (ok[1]) svd3_complete_two<1>(U, true);
-        else svd3_complete_two<0>(U, ok[0]);
-    }
+    if (nbad == 1) svd3_complete_one(U, !ok[0] ? 0 : (!ok[1] ? 1 : 2));
+    else if (nbad >= 2) svd3_complete_two(U, ok[2] ? 2 : (ok[1] ? 1 : 0), ok[2] || ok[1] || ok[0]);
 }
 
 __host__ __device__ inline void mat3_mul(const double A[9], const double B[9], double C[9]) {
