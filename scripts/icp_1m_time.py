@@ -12,7 +12,7 @@ index = pcp.TargetIndex(pcp.DeviceCloud.upload(world, ctx), ctx=ctx)
 for rep in range(6):
     sd = pcp.DeviceCloud.upload(src, ctx).prepare(index)
     ctx.sync(); t0 = time.perf_counter()
-    r = pcp.icp_device(sd, index, np.eye(4), mode="total", max_iter=20, r_thres=-1.0, t_thres=-1.0, max_d2=1.0, min_iter=20)
+    r = pcp.icp_device(sd, index, np.eye(4), mode="total", max_iter=20, r_thres=-1.0, t_thres=-1.0, max_d2=float(os.environ.get("MAX_D2", 1.0)), min_iter=20)
     ctx.sync(); w = time.perf_counter() - t0
     print("rep", rep, "device ms/iter %.3f wall ms/iter %.3f n_assoc %d" % (r["device_ms"] / r["iters"], 1e3 * w / r["iters"], r["n_assoc"]), flush=True)
     sd.free()
