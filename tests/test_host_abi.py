@@ -46,6 +46,45 @@ def test_host_only_entry_points(pcp):
         assert np.allclose(pcp.homo2tq(T), tq, rtol=0, atol=1e-15)
 
 
+def test_procrustes_rank_deficient_inputs(pcp):
+    """Planar, collinear and single-point correspondences (H of rank 2, 1, 0: main.py:131-141 does not special-case them, numpy's
+    SVD completes U and V somehow): R must be orthogonal and the transform must reproduce B on the data itself.  These are the inputs
+    of pcr_linalg.h's completion of U, the code that was rewritten (selects on scalars instead of variable-index stores) to keep
+    every ICP kernel free of scratch memory."""
+    rng = np.random.default_rng(3)
+
+    def rot(axis, ang):
+        a = np.asarray(axis, float)
+        a /= np.linalg.norm(a)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+    for case in range(120):
+        kind = case % 4
+        if kind == 0:    # a plane in general position, or an axis-aligned one
+            n = rng.normal(size=3)
+            n /= np.linalg.norm(n)
+            e1 = np.cross(n, [1.0, 0.0, 0.0])
+            e1 /= np.linalg.norm(e1)
+            A = np.outer(e1, rng.normal(size=40)) + np.outer(np.cross(n, e1), rng.normal(size=40))
+            if case % 8 == 0:
+                A = np.vstack([rng.normal(size=40), rng.normal(size=40), np.zeros(40)])
+        elif kind == 1:  # a line
+            d = rng.normal(size=3) if case % 8 != 1 else np.array([0.0, 1.0, 0.0])
+            A = np.outer(d, rng.normal(size=40))
+        elif kind == 2:  # one point, repeated
+            A = np.outer(rng.normal(size=3), np.ones(40))
+        else:            # full rank, for comparison
+            A = rng.normal(size=(3, 40))
+        R0 = rot(rng.normal(size=3), rng.uniform(0.0, 3.0))
+        B = R0 @ A + rng.normal(size=(3, 1))
+        R, t, cost = pcp.procrustes_transformation(A, B)
+        assert np.isfinite(R).all() and np.isfinite(t).all() and np.isfinite(cost), (case, kind)
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12, (case, kind)
+        assert np.abs(R @ A + t - B).max() < 1e-9 * max(1.0, np.abs(B).max()), (case, kind, np.abs(R @ A + t - B).max())
+        assert cost < 1e-6, (case, kind, cost)
+
+
 def test_csv_format_matches_reference(pcp, tmp_path):
     p = load_golden("pose_utils.npz")
     rows = np.zeros((len(p["T"]), 9))
