@@ -111,17 +111,26 @@ __device__ static sum3 pw_leaf8(const coord_view& a, unsigned int off, unsigned 
     return res;
 }
 
-// (off, n) and the control flow below are the same in the eight lanes of a voxel
-__device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int n, int lane8) {
+// (off, n) and the control flow below are the same in the eight lanes of a voxel.
+// The explicit stack of the recursion lives in LDS, one per voxel group of eight lanes (written by its lane 0, read by all eight): as a
+// local array it was 1 616 bytes of SCRATCH per lane -- 103 KB per wave for a path only voxels of more than 128 points ever take --,
+// and a kernel that uses scratch pays for it at its first dispatch after kernels that do not.
+struct pw_frame { unsigned int off, n; int state; int pad; sum3 left; };
+constexpr int PW_DEPTH = 28;   // n < 2^32 halves to <= 128 in 25 steps
+__device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int n, int lane8, pw_frame* st) {
     if (n <= 128) return pw_leaf8(a, 0, n, lane8);
     // explicit stack for: sum(off, n) = n <= 128 ? leaf : sum(off, n2) + sum(off + n2, n - n2), n2 = (n/2) rounded down to 8
-    struct frame { unsigned int off, n; int state; sum3 left; };
-    frame st[40];
     int sp = 0;
-    st[sp++] = {0u, n, 0, {0.0, 0.0, 0.0}};
+    if (lane8 == 0) st[0] = pw_frame{0u, n, 0, 0, {0.0, 0.0, 0.0}};
+    sp = 1;
     sum3 ret = {0.0, 0.0, 0.0};
     while (sp > 0) {
-        frame& f = st[sp - 1];
+        // (LDS operations of a wave execute in order, so lane 0's store is seen by the group's other lanes without a hardware wait;
+        // the fences keep the COMPILER from holding a frame in registers across the store another lane made)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const pw_frame f = st[sp - 1];
         if (f.n <= 128) {
             ret = pw_leaf8(a, f.off, f.n, lane8);
             --sp;
@@ -130,12 +139,11 @@ __device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int n, i
         unsigned int n2 = f.n / 2;
         n2 -= n2 % 8;
         if (f.state == 0) {
-            f.state = 1;
-            st[sp++] = {f.off, n2, 0, {0.0, 0.0, 0.0}};
+            if (lane8 == 0) { st[sp - 1].state = 1; st[sp] = pw_frame{f.off, n2, 0, 0, {0.0, 0.0, 0.0}}; }
+            ++sp;
         } else if (f.state == 1) {
-            f.left = ret;
-            f.state = 2;
-            st[sp++] = {f.off + n2, f.n - n2, 0, {0.0, 0.0, 0.0}};
+            if (lane8 == 0) { st[sp - 1].left = ret; st[sp - 1].state = 2; st[sp] = pw_frame{f.off + n2, f.n - n2, 0, 0, {0.0, 0.0, 0.0}}; }
+            ++sp;
         } else {
             ret.x = f.left.x + ret.x; ret.y = f.left.y + ret.y; ret.z = f.left.z + ret.z;
             --sp;
@@ -167,6 +175,8 @@ voxel_gather_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restri
 __global__ void __launch_bounds__(256)
 voxel_emit_kernel(const vox_xyz* __restrict__ xyz, const unsigned int* __restrict__ heads, const unsigned int* __restrict__ n_groups_p, long long n, int mode,
                   unsigned long long seed, pcr_pt* __restrict__ out_pts, double* __restrict__ out_xyz) {
+    __shared__ pw_frame s_stack[256 / 8][PW_DEPTH];
+    pw_frame* const st = s_stack[threadIdx.x >> 3];
     const unsigned int ng = *n_groups_p;
     const int lane8 = threadIdx.x & 7;
     if (ng == 0) return;
@@ -185,7 +195,7 @@ voxel_emit_kernel(const vox_xyz* __restrict__ xyz, const unsigned int* __restric
         ox /= (double)cnt; oy /= (double)cnt; oz /= (double)cnt;
     } else if (mode == 0) {
         const coord_view a{xyz + s};
-        const sum3 t = numpy_pairwise_sum(a, cnt, lane8);
+        const sum3 t = numpy_pairwise_sum(a, cnt, lane8, st);
         ox = t.x / (double)cnt; oy = t.y / (double)cnt; oz = t.z / (double)cnt;
     } else {
         const unsigned int k = (unsigned int)(splitmix64(seed ^ ((unsigned long long)v * 0xD1B54A32D192ED03ull)) % cnt);
