@@ -138,10 +138,16 @@ __device__ static void smallest_eigvec(const double S[6], double n[3]) {
             }
         }
     }
-    int m = 0;
-    if (A[1][1] < A[m][m]) m = 1;
-    if (A[2][2] < A[m][m]) m = 2;
-    n[0] = Q[0][m]; n[1] = Q[1][m]; n[2] = Q[2][m];
+    // (selects on values read into scalars first, not Q[i][m] with a run-time m: a dynamically indexed local array lives in scratch
+    // memory -- 112 bytes per lane for this kernel)
+    const double a0 = A[0][0], a1 = A[1][1], a2 = A[2][2];
+    const bool m1 = a1 < a0;
+    const double am = m1 ? a1 : a0;
+    const bool m2 = a2 < am;
+    const double q00 = Q[0][0], q01 = Q[0][1], q02 = Q[0][2], q10 = Q[1][0], q11 = Q[1][1], q12 = Q[1][2], q20 = Q[2][0], q21 = Q[2][1], q22 = Q[2][2];
+    n[0] = m2 ? q02 : (m1 ? q01 : q00);
+    n[1] = m2 ? q12 : (m1 ? q11 : q10);
+    n[2] = m2 ? q22 : (m1 ? q21 : q20);
 }
 
 // ------------------------------------------------------------ hybrid normals
@@ -175,7 +181,8 @@ __global__ void __launch_bounds__(64) hybrid_normals_kernel(pcr_grid_view gv, lo
             if (d < 0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
         }
     }
-    if (threadIdx.x < 3) normals[3 * p.id + threadIdx.x] = nrm[threadIdx.x];
+    const double n0 = nrm[0], n1 = nrm[1], n2 = nrm[2];
+    if (threadIdx.x < 3) normals[3 * p.id + threadIdx.x] = threadIdx.x == 0 ? n0 : (threadIdx.x == 1 ? n1 : n2);
 }
 
 // ---------------------------------------------------------------------- SPFH
