@@ -928,7 +928,7 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
                 }
                 jj[u] = L->fl_start[lo] + (t - L->fl_off[lo]);
             }
-            pcr_pt b0, b1;
+            pcr_pt b0 = pcr_pt{0.0, 0.0, 0.0, 0}, b1 = pcr_pt{0.0, 0.0, 0.0, 0};   // (assigned on every path: see the staging rounds of the tile)
             if (ok[0]) b0 = gv.pts[jj[0]];
             if (ok[1]) b1 = gv.pts[jj[1]];
             if (ok[0]) {

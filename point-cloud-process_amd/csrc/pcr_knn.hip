@@ -236,7 +236,7 @@ radius_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq
 #define PCR_KNN_LV 3
 #endif
 template <int K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 4 : 2, 8)))   // (k <= 8: 129 VGPRs without the hint, one too many for four waves per SIMD)
 knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq, int k, int* __restrict__ idx_out,
                  double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count,
                  const int* __restrict__ todo /* query ids to do (what the wave tiles left), or null: all */, const unsigned int* __restrict__ todo_count,
@@ -277,8 +277,10 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
                 for (unsigned int j0 = s; j0 < e; j0 += 4) {
                     pcr_pt rec[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 4; ++u) {   // (assigned on every path: conditionally unassigned records become loop-carried registers)
+                        rec[u] = pcr_pt{0.0, 0.0, 0.0, 0};
                         if (j0 + u < e) rec[u] = gv.pts[j0 + u];
+                    }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (j0 + u >= e) break;

@@ -115,8 +115,10 @@ normals_kernel(pcr_grid_view gv, long long n, double* __restrict__ normals /* by
         for (unsigned int j0 = s; j0 < e; j0 += 4) {   // four records per trip, requested together
             pcr_pt rec[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {   // (assigned on every path: conditionally unassigned records become loop-carried registers)
+                rec[u] = pcr_pt{0.0, 0.0, 0.0, 0};
                 if (j0 + u < e) rec[u] = gv.pts[j0 + u];
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (j0 + u >= e) break;
