@@ -260,6 +260,63 @@ PCR_API int pcr_ransac_default_params(pcr_ransac_params* p);
 PCR_API int pcr_ransac(pcr_ctx* ctx, const pcr_cloud* source, const pcr_cloud* target, const int32_t* corr, int64_t m,
                        const pcr_ransac_params* params, pcr_ransac_result* result);
 
+/* Device-resident variant of the same stage -- what the pair loop main.py:190-216 runs per pair, without a host round trip
+ * between its steps.
+ * pcr_preprocess = preprocess_point_cloud(pcd, voxel_size) (main.py:33-47): voxel_down_sample(voxel_size) (mode 2 of
+ *   pcr_voxel_filter), estimate_normals(Hybrid(normal_radius, normal_max_nn)) oriented toward the origin,
+ *   compute_fpfh_feature(Hybrid(fpfh_radius, fpfh_max_nn)); main.py:39,44 use 2 x / 5 x voxel_size and 30 / 100.  The result
+ *   (down-sampled cloud, normals, 33-d descriptors) stays on the device in a pcr_prep, to be used for every pair the scan
+ *   takes part in (342 pairs over 504 scans in Registration/reg_result.txt).  A pcr_prep belongs to the context that made it
+ *   (pcr_prep_free with that context) but may be READ by any context of the same device once pcr_preprocess has returned.
+ * pcr_global_registration = execute_global_registration (main.py:68-84): nearest descriptors both ways, mutual filter (falls
+ *   back to the one-way set below 9 survivors, like Open3D), pcr_ransac's loop over that set; result->reserved_i = size of
+ *   the correspondence set.  The final whole-cloud evaluation Open3D appends (fitness / inlier_rmse of the RegistrationResult)
+ *   is not part of it: main.py:211 reads .transformation only.                                                            */
+typedef struct pcr_prep pcr_prep;
+PCR_API int pcr_preprocess(pcr_ctx* ctx, const pcr_cloud* cloud, double voxel_size, double normal_radius, int normal_max_nn,
+                           double fpfh_radius, int fpfh_max_nn, pcr_prep** out);
+PCR_API int64_t pcr_prep_size(const pcr_prep* prep);
+PCR_API const pcr_cloud* pcr_prep_cloud(const pcr_prep* prep);   /* the down-sampled cloud (owned by the prep) */
+/* points (n,3), normals (n,3), features (n,33) row-major; any of them may be NULL */
+PCR_API int pcr_prep_download(pcr_ctx* ctx, const pcr_prep* prep, double* points, double* normals, double* features);
+PCR_API int pcr_prep_free(pcr_ctx* ctx, pcr_prep* prep);
+PCR_API int pcr_global_registration(pcr_ctx* ctx, const pcr_prep* source, const pcr_prep* target, const pcr_ransac_params* params,
+                                    int mutual_filter, pcr_ransac_result* result);
+
+/* The whole pair loop of Registration/main.py:183-216 over a table of scans: pairs[i] = (source scan, target scan) as indices
+ * into clouds[] (the rows "trg,src" of the pair list, main.py:186-194; clouds[] = the <id>.bin files read by read_bin_velodyne,
+ * main.py:10-17).  A scan that takes part in several pairs (Registration/reg_result.txt: 342 pairs over 504 scans) is uploaded
+ * and, with `global`, preprocessed ONCE per call and kept on the device while the call runs.
+ *   global != NULL: prepare_dataset + execute_global_registration (main.py:196-203) give the initial transform of every pair
+ *     whose T0 is NULL: pcr_preprocess of every scan such a pair uses, pcr_global_registration per pair (the same ransac seed
+ *     for every pair, so a pair's result does not depend on which other pairs share the call); a pair for which no hypothesis
+ *     passes the checkers starts from identity.  T_init_out (n_pairs x 16, may be NULL) receives the transforms ICP started from.
+ *   then icp_point2point (main.py:211) for every pair through pcr_icp_batch's fused stages.
+ * results / status_out as pcr_icp_batch.                                                                                   */
+typedef struct pcr_cloud_ref {
+    const float* xyz;     /* n records of `stride` floats, x, y, z first */
+    int64_t n;
+    int64_t stride;
+} pcr_cloud_ref;
+typedef struct pcr_pair_ref {
+    int32_t src, tgt;     /* rows of clouds[] */
+    const double* T0;     /* 16 doubles, row-major, or NULL (identity, or the global registration's result) */
+} pcr_pair_ref;
+typedef struct pcr_global_params {
+    double voxel_size;        /* main.py:196 -> 2.0 */
+    double normal_radius;     /* main.py:38  -> voxel_size * 2 */
+    double fpfh_radius;       /* main.py:43  -> voxel_size * 5 */
+    int32_t normal_max_nn;    /* main.py:40  -> 30 */
+    int32_t fpfh_max_nn;      /* main.py:46  -> 100 */
+    int32_t mutual_filter;    /* main.py:74  -> 1 */
+    int32_t reserved_i;
+    pcr_ransac_params ransac; /* main.py:70-83 -> max_distance voxel_size * 1.5, edge 0.9, 100000 iterations / 0.999 */
+} pcr_global_params;
+PCR_API int pcr_global_default_params(double voxel_size, pcr_global_params* p);
+PCR_API int pcr_register_pairs(pcr_ctx* const* ctxs, int n_ctx, const pcr_cloud_ref* clouds, int64_t n_clouds, const pcr_pair_ref* pairs,
+                               int64_t n_pairs, const pcr_global_params* global, const pcr_icp_params* icp, pcr_icp_result* results,
+                               int32_t* status_out, double* T_init_out);
+
 /* ------------------------------------------------------------------ DBSCAN
  * DBSCAN.fit (Cluster_dbscan/dbscan.py:10-36), a consumer of the radius query:
  * labels_out[n] = cluster id per row (-1 noise), numbered in the reference's

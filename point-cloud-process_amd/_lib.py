@@ -84,6 +84,27 @@ class Pair(C.Structure):
     ]
 
 
+class CloudRef(C.Structure):
+    _fields_ = [("xyz", C.POINTER(C.c_float)), ("n", C.c_int64), ("stride", C.c_int64)]
+
+
+class PairRef(C.Structure):
+    _fields_ = [("src", C.c_int32), ("tgt", C.c_int32), ("T0", C.POINTER(C.c_double))]
+
+
+class GlobalParams(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_double),
+        ("normal_radius", C.c_double),
+        ("fpfh_radius", C.c_double),
+        ("normal_max_nn", C.c_int32),
+        ("fpfh_max_nn", C.c_int32),
+        ("mutual_filter", C.c_int32),
+        ("reserved_i", C.c_int32),
+        ("ransac", RansacParams),
+    ]
+
+
 class IcpResult(C.Structure):
     _fields_ = [
         ("T", C.c_double * 16),
@@ -135,6 +156,9 @@ SIGNATURES = {
     "pcr_icp_default_params": (None, [C.POINTER(IcpParams)]),
     "pcr_icp": (C.c_int, [_vp, _vp, _vp, C.POINTER(IcpParams), _dp, C.POINTER(IcpResult)]),
     "pcr_icp_batch": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(Pair), C.c_int64, C.POINTER(IcpParams), C.POINTER(IcpResult), _ip]),
+    "pcr_global_default_params": (C.c_int, [C.c_double, C.POINTER(GlobalParams)]),
+    "pcr_register_pairs": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(CloudRef), C.c_int64, C.POINTER(PairRef), C.c_int64, C.POINTER(GlobalParams),
+                                     C.POINTER(IcpParams), C.POINTER(IcpResult), _ip, _dp]),
     "pcr_icp_moments": (C.c_int, [_vp, _vp, _vp, _dp, C.c_double, _dp, _dp, _dp]),
     "pcr_procrustes": (C.c_int, [_dp, _dp, C.c_int64, _dp, _dp, _dp]),
     "pcr_homo2tq": (C.c_int, [_dp, _dp]),
@@ -149,6 +173,12 @@ SIGNATURES = {
     "pcr_feature_match": (C.c_int, [_vp, _dp, C.c_int64, _dp, C.c_int64, C.c_int, _ip, _dp]),
     "pcr_ransac_default_params": (C.c_int, [C.POINTER(RansacParams)]),
     "pcr_ransac": (C.c_int, [_vp, _vp, _vp, _ip, C.c_int64, C.POINTER(RansacParams), C.POINTER(RansacResult)]),
+    "pcr_preprocess": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.POINTER(_vp)]),
+    "pcr_prep_size": (C.c_int64, [_vp]),
+    "pcr_prep_cloud": (_vp, [_vp]),
+    "pcr_prep_download": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
+    "pcr_prep_free": (C.c_int, [_vp, _vp]),
+    "pcr_global_registration": (C.c_int, [_vp, _vp, _vp, C.POINTER(RansacParams), C.c_int, C.POINTER(RansacResult)]),
     "pcr_dbscan": (C.c_int, [_vp, _vp, C.c_double, C.c_int, _ip, _ip]),
     "pcr_debug_read": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int64]),
     "pcr_profile_enable": (C.c_int, [_vp, C.c_int]),

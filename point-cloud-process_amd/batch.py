@@ -68,13 +68,16 @@ def gpu_register_fn(device=0, nn="grid", mode="compat", streams=1, **icp_kw):
     return run
 
 
-# NumPy mirrors of pcr_pair / pcr_icp_result (include/pcr.h); their sizes are asserted against the ctypes structures on first use
-_PAIR_DT = np.dtype([("src", "u8"), ("n_src", "i8"), ("stride_src", "i8"), ("tgt", "u8"), ("n_tgt", "i8"), ("stride_tgt", "i8"), ("T0", "u8")])
+# NumPy mirrors of pcr_cloud_ref / pcr_pair_ref / pcr_icp_result (include/pcr.h); their sizes are asserted against the ctypes structures on first use
+_PAIR_DT = np.dtype([("src", "u8"), ("n_src", "i8"), ("stride_src", "i8"), ("tgt", "u8"), ("n_tgt", "i8"), ("stride_tgt", "i8"), ("T0", "u8")])   # pcr_pair (pcr_icp_batch)
+_CLOUD_DT = np.dtype([("xyz", "u8"), ("n", "i8"), ("stride", "i8")])
+_PAIRREF_DT = np.dtype([("src", "i4"), ("tgt", "i4"), ("T0", "u8")])
 _RESULT_DT = np.dtype([("T", "f8", 16), ("T_total", "f8", 16), ("iters", "i4"), ("status", "i4"), ("n_assoc", "i8"), ("cost", "f8"), ("mean_d2", "f8"),
                        ("r_diff", "f8", 256), ("t_diff", "f8", 256), ("device_ms", "f8"), ("nn_kernel_ms", "f8"), ("nn_launches", "i4"), ("reserved", "i4")])
 _ctx_pool = {}
 _ctx_pool_lock = threading.Lock()
 _batch_lock = threading.Lock()
+native_calls = []   # (first pair id, pairs, scans, with global initialisation) of every native batch call of this process: what the tests' spies read
 
 
 def _pooled_contexts(device, n):
@@ -89,57 +92,103 @@ def _pooled_contexts(device, n):
         return have[:n]
 
 
+def global_params(voxel_size=2.0, seed=0, **kw):
+    """pcr_global_params with the values of Registration/main.py:33-84,196 (voxel 2.0 -> normals 4.0 / 30, FPFH 10.0 / 100, RANSAC 3.0 m,
+    0.9, 100 000 / 0.999); keyword overrides: normal_radius, fpfh_radius, normal_max_nn, fpfh_max_nn, mutual_filter, max_iteration,
+    confidence, max_distance, edge_similarity, check_distance."""
+    import ctypes as C
+
+    from . import _lib as L
+    g = L.GlobalParams()
+    L.check(L.lib().pcr_global_default_params(float(voxel_size), C.byref(g)))
+    g.ransac.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    for k, v in kw.items():
+        if hasattr(g, k) and k != "ransac":
+            setattr(g, k, type(getattr(g, k))(v))
+        elif hasattr(g.ransac, k):
+            setattr(g.ransac, k, type(getattr(g.ransac, k))(v))
+        else:
+            raise TypeError(f"unknown global-initialisation parameter {k!r}")
+    return g
+
+
 def native_register_share(pairs, device=0, streams=8, mode="compat", max_iter=100, r_thres=0.5, t_thres=0.5, max_d2=5.0,
-                          r_metric="frobenius", min_iter=0, nn="grid", as_table=False, first_id=0):
-    """The local share of a batch through ONE C call (pcr_icp_batch): `streams` contexts on `device` and as many native
-    threads, which pack the clouds of a sub-batch (64 pairs) together and run every stage -- keys, one sort, the grids of all
-    targets, every ICP pass, the Procrustes steps -- as one launch for all its pairs (csrc/pcr_batch.hip); no interpreter in
-    the loop, results bit-identical to pcr_icp on each pair alone.
+                          r_metric="frobenius", min_iter=0, nn="grid", as_table=False, first_id=0, global_init=None, return_init=False):
+    """The local share of a batch through ONE C call (pcr_register_pairs): `streams` contexts on `device` and as many native
+    threads.  The clouds of the share form a SCAN TABLE -- arrays that are the same object (or the same memory) are the same scan,
+    uploaded and, with `global_init`, preprocessed once however many pairs use it (Registration/reg_result.txt: 342 pairs over 504
+    scans) --; `global_init` (a dict for global_params(), or True) runs prepare_dataset + execute_global_registration
+    (main.py:196-203) for every pair without a T0; then the fused batch stages register every pair (csrc/pcr_batch.hip): no
+    interpreter in the loop, results bit-identical to pcr_icp on each pair alone.
     `pairs`: (src (N,>=3) float32, tgt (M,>=3) float32, T0 or None).  Returns result dicts in input order."""
     import ctypes as C
 
     from . import _lib as L
     if nn != "grid":
         raise ValueError("the native batch path uses the grid index")
-    assert _PAIR_DT.itemsize == C.sizeof(L.Pair) and _RESULT_DT.itemsize == C.sizeof(L.IcpResult), "batch.py dtypes out of step with include/pcr.h"
+    assert (_CLOUD_DT.itemsize == C.sizeof(L.CloudRef) and _PAIRREF_DT.itemsize == C.sizeof(L.PairRef) and
+            _RESULT_DT.itemsize == C.sizeof(L.IcpResult)), "batch.py dtypes out of step with include/pcr.h"
     n = len(pairs)
     if n == 0:
         return []
     ctxs = _pooled_contexts(device, max(1, min(int(streams), n)))
     with _batch_lock:   # the pooled contexts are not thread-safe: one batch at a time per process
-        # the pair table and the result table are NumPy structured arrays laid out like pcr_pair / pcr_icp_result: filling and
-        # reading them costs a few microseconds per pair instead of ~200 through ctypes attribute access
-        # (columns, not rows: a structured row assignment costs ~3 us, an __array_interface__ dictionary ~1.8 us; at 40 000 pairs/s
-        # the table building was a quarter of the call)
-        cols = [[0] * n for _ in range(7)]
+        # scan table + pair table as NumPy structured arrays laid out like the C structures, filled column-wise (a ctypes attribute
+        # access costs ~200 ns, a structured row assignment ~3 us: at 40 000 pairs/s the table building was a quarter of the call)
+        scans = {}          # id(array) -> row (an array handed in for several pairs is one scan)
+        by_mem = {}         # (address, n, stride) -> row (views of the same memory too)
+        c_ptr, c_n, c_st = [], [], []
+        p_src, p_tgt, p_T0 = [0] * n, [0] * n, [0] * n
         keep = []
         f32 = np.dtype(np.float32)
-        for i, (src, tgt, T0) in enumerate(pairs):
-            s = src if (type(src) is np.ndarray and src.dtype == f32 and src.flags.c_contiguous) else np.ascontiguousarray(src, dtype=np.float32)
-            t = tgt if (type(tgt) is np.ndarray and tgt.dtype == f32 and tgt.flags.c_contiguous) else np.ascontiguousarray(tgt, dtype=np.float32)
-            ss, ts = s.shape, t.shape
-            if len(ss) != 2 or len(ts) != 2 or ss[1] < 3 or ts[1] < 3:
+
+        def scan_row(a):
+            row = scans.get(id(a))
+            if row is not None:
+                return row
+            s = a if (type(a) is np.ndarray and a.dtype == f32 and a.flags.c_contiguous) else np.ascontiguousarray(a, dtype=np.float32)
+            sh = s.shape
+            if len(sh) != 2 or sh[1] < 3:
                 raise ValueError("pairs must hold (N, >= 3) arrays")
-            keep.append((s, t))
-            cols[0][i], cols[1][i], cols[2][i] = s.ctypes.data, ss[0], ss[1]
-            cols[3][i], cols[4][i], cols[5][i] = t.ctypes.data, ts[0], ts[1]
+            key = (s.__array_interface__["data"][0], sh[0], sh[1])
+            row = by_mem.get(key)
+            if row is None:
+                row = len(c_ptr)
+                by_mem[key] = row
+                c_ptr.append(key[0]); c_n.append(sh[0]); c_st.append(sh[1])
+            keep.append(s)
+            if s is a:
+                scans[id(a)] = row     # (a converted copy is a fresh scan each time: its source may be anything)
+            return row
+
+        for i, (src, tgt, T0) in enumerate(pairs):
+            p_src[i] = scan_row(src)
+            p_tgt[i] = scan_row(tgt)
             if T0 is not None:
                 T0c = L.as_f64(T0).reshape(16)
                 keep.append(T0c)
-                cols[6][i] = T0c.ctypes.data
-        parr = np.zeros(n, dtype=_PAIR_DT)
-        for name, col in zip(_PAIR_DT.names, cols):
-            parr[name] = col
+                p_T0[i] = T0c.__array_interface__["data"][0]
+        carr = np.zeros(len(c_ptr), dtype=_CLOUD_DT)
+        carr["xyz"], carr["n"], carr["stride"] = c_ptr, c_n, c_st
+        parr = np.zeros(n, dtype=_PAIRREF_DT)
+        parr["src"], parr["tgt"], parr["T0"] = p_src, p_tgt, p_T0
         p = L.IcpParams()
         L.lib().pcr_icp_default_params(C.byref(p))
         p.max_iter, p.r_thres, p.t_thres, p.max_d2, p.min_iter = int(max_iter), float(r_thres), float(t_thres), float(max_d2), int(min_iter)
         p.mode = L.PCR_ICP_COMPAT_MAIN if mode == "compat" else L.PCR_ICP_TOTAL
         p.r_metric = L.PCR_RMETRIC_GEODESIC if r_metric == "geodesic" else L.PCR_RMETRIC_FROBENIUS
+        gp = None
+        if global_init:
+            gp = global_init if isinstance(global_init, L.GlobalParams) else global_params(**(global_init if isinstance(global_init, dict) else {}))
         res = np.zeros(n, dtype=_RESULT_DT)
         status = np.zeros(n, dtype=np.int32)
+        T_init = np.zeros((n, 16)) if (return_init or gp is not None) else None
         handles = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
-        rc = L.lib().pcr_icp_batch(handles, len(ctxs), parr.ctypes.data_as(C.POINTER(L.Pair)), n, C.byref(p),
-                                   res.ctypes.data_as(C.POINTER(L.IcpResult)), L.iptr(status))
+        native_calls.append((int(first_id), n, len(c_ptr), gp is not None))
+        del native_calls[:-64]
+        rc = L.lib().pcr_register_pairs(handles, len(ctxs), carr.ctypes.data_as(C.POINTER(L.CloudRef)), len(c_ptr),
+                                        parr.ctypes.data_as(C.POINTER(L.PairRef)), n, C.byref(gp) if gp is not None else None, C.byref(p),
+                                        res.ctypes.data_as(C.POINTER(L.IcpResult)), L.iptr(status), L.dptr(T_init) if T_init is not None else None)
         L.check(rc, ctxs[0].handle)
         if as_table:   # (n, RECORD) rows like pack_result's, built column-wise
             table = np.zeros((n, RECORD))
@@ -147,14 +196,22 @@ def native_register_share(pairs, device=0, streams=8, mode="compat", max_iter=10
             table[:, 1:17] = res["T"]
             table[:, 17], table[:, 18], table[:, 19] = res["iters"], res["status"], res["n_assoc"]
             table[:, 20], table[:, 21] = res["cost"], res["mean_d2"]
-            return table
+            return (table, T_init.reshape(n, 4, 4)) if return_init else table
         T, Tt = res["T"].reshape(n, 4, 4), res["T_total"].reshape(n, 4, 4)
-        return [{"T": T[i], "T_total": Tt[i], "iters": int(res["iters"][i]), "status": int(res["status"][i]), "n_assoc": int(res["n_assoc"][i]),
-                 "cost": float(res["cost"][i]), "mean_d2": float(res["mean_d2"][i])} for i in range(n)]
+        out = [{"T": T[i], "T_total": Tt[i], "iters": int(res["iters"][i]), "status": int(res["status"][i]), "n_assoc": int(res["n_assoc"][i]),
+                "cost": float(res["cost"][i]), "mean_d2": float(res["mean_d2"][i])} for i in range(n)]
+        if T_init is not None:
+            for i, o in enumerate(out):
+                o["T_init"] = T_init[i].reshape(4, 4)
+        return out
 
 
-def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, **kw):
+def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, global_init=None, **kw):
     """Register ``pairs`` = sequence of (src (N,3+), tgt (M,3+), T0 or None).
+
+    ``global_init`` (True, or a dict of global_params() overrides): pairs without a T0 start from the reference's own
+    initialisation (prepare_dataset + execute_global_registration, Registration/main.py:196-203), computed INSIDE the rank's
+    native call for its own share only; needs float32 clouds (the native path).
 
     Without torch.distributed (or world size 1) everything runs on this process's GPU.  Inside an
     initialised process group every rank must call this with the SAME ``pairs`` list (or at least a
@@ -185,7 +242,11 @@ def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, 
         native = kw.get("nn", "grid") == "grid" and all(
             getattr(pairs[i][0], "dtype", None) == np.float32 and getattr(pairs[i][1], "dtype", None) == np.float32 for i in range(lo, hi))
         if not native:
+            if global_init:
+                raise ValueError("global_init needs the native batch path: float32 clouds and the grid index")
             register_fn = gpu_register_fn(device=device, streams=streams, **kw)
+    elif global_init:
+        raise ValueError("global_init is computed by the native worker: do not pass register_fn with it")
     workers = int(getattr(register_fn, "streams", 1))
     local = np.zeros((hi - lo, RECORD))
     # A pcr_ctx is not thread-safe: a slot (= one context, one HIP stream) belongs to exactly one task at a time.
@@ -206,7 +267,7 @@ def register_batch(pairs, register_fn=None, group=None, device=None, streams=8, 
 
     if native:
         if hi > lo:
-            local = native_register_share(pairs[lo:hi], device=device, streams=streams, as_table=True, first_id=lo, **kw)
+            local = native_register_share(pairs[lo:hi], device=device, streams=streams, as_table=True, first_id=lo, global_init=global_init, **kw)
     elif workers > 1 and hi - lo > 1:
         with ThreadPoolExecutor(max_workers=workers) as pool:
             list(pool.map(one, range(lo, hi)))

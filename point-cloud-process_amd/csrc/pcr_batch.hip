@@ -38,9 +38,13 @@ constexpr unsigned long long MORTON_BIAS3 = 7ull << 60;   // spread21(PCR_COORD_
 
 struct batch_cloud {          // one per cloud of a sub-batch: sources [0, m), targets [m, 2m)
     unsigned long long off;   // first record slot (multiple of SLOT)
-    long long n;
+    long long n;              // points that take part in the fused stages (0: the pair is left to the per-pair path)
+    long long n_copy;         // points the key kernel brings over to the device (>= n: a scan later sub-batches share is brought over
+                              // even when its own pair is not taken)
     double lo[3];             // origin of the cloud's Morton curve (its bounding box's min corner)
     double inv;               // 1 / cell of the curve
+    const float* src;         // the cloud's packed coordinates (12 B per point) as the key kernel reads them: this sub-batch's mapped
+                              // staging block (over PCIe), or the device copy an earlier sub-batch of the call made of the same scan
 };
 struct batch_target {         // per pair: what the plan kernel needs to write the pair's descriptor
     double cell, hi[3];
@@ -74,11 +78,12 @@ __device__ inline int cloud_of_block(const batch_cloud* __restrict__ cl, int n_c
     return s_c;
 }
 
-// `xyz_host`: the packed coordinates in pinned, device-mapped host memory, read over PCIe by this kernel (no copy engine: copies
-// of several contexts queue behind each other in the runtime, and sometimes for milliseconds); `xyz_dev` receives the device
-// copy the gather reads later.
+// Every cloud's packed coordinates are read through its own pointer: pinned, device-mapped host memory, read over PCIe by this
+// kernel (no copy engine: copies of several contexts queue behind each other in the runtime, and sometimes for milliseconds), or
+// -- a scan that an earlier sub-batch of the call already brought over (Registration/reg_result.txt: 342 pairs over 504 scans) --
+// that sub-batch's device copy.  `xyz_dev` receives this sub-batch's device copy, which the gather reads later.
 __global__ void __launch_bounds__(SLOT)
-batch_keys_kernel(const float* xyz_host, float* xyz_dev, const batch_cloud* __restrict__ cl, int n_clouds, int mbits, unsigned int n_blocks,
+batch_keys_kernel(float* xyz_dev, const batch_cloud* __restrict__ cl, int n_clouds, int mbits, unsigned int n_blocks,
                   unsigned long long* __restrict__ keys, unsigned int* __restrict__ vals) {
     // A FEW blocks stride over the slots: the kernel is bound by PCIe (56 GB/s: a few thousand loads in flight saturate it), and
     // launched one block per 256 records its waiting waves fill every wave slot of the chip -- the sort, grid and pass kernels of the
@@ -89,14 +94,17 @@ batch_keys_kernel(const float* xyz_host, float* xyz_dev, const batch_cloud* __re
         const int c = cloud_of_block(cl, n_clouds, (unsigned long long)blk * SLOT);
         const batch_cloud C = cl[c];
         unsigned long long k = mask;   // padding of the slot: behind every point of its cloud (the sort is stable)
-        if (i - C.off < (unsigned long long)C.n) {
-            const float x = xyz_host[3 * i], y = xyz_host[3 * i + 1], z = xyz_host[3 * i + 2];
-            if (xyz_dev != xyz_host) { xyz_dev[3 * i] = x; xyz_dev[3 * i + 1] = y; xyz_dev[3 * i + 2] = z; }
+        if (i - C.off < (unsigned long long)C.n_copy) {
+            const float* const p = C.src + 3 * (i - C.off);
+            const float x = p[0], y = p[1], z = p[2];
+            if (xyz_dev + 3 * i != p) { xyz_dev[3 * i] = x; xyz_dev[3 * i + 1] = y; xyz_dev[3 * i + 2] = z; }
+            if (i - C.off < (unsigned long long)C.n) {
             bool clamped = false;
             const unsigned long long cx = (unsigned long long)cell_coord((double)x, C.lo[0], C.inv, &clamped);
             const unsigned long long cy = (unsigned long long)cell_coord((double)y, C.lo[1], C.inv, &clamped);
             const unsigned long long cz = (unsigned long long)cell_coord((double)z, C.lo[2], C.inv, &clamped);
             k = (spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2)) & mask;
+            }
         }
         keys[i] = ((unsigned long long)c << mbits) | k;
         vals[i] = (unsigned int)i;
@@ -343,15 +351,46 @@ unsigned int next_pow2_host(unsigned long long v) {
 
 using dev_block = pcr_dev_block;
 
+// One scan of the call's table as the sub-batches see it: the sub-batch that uses it FIRST (its owner: fixed before any thread
+// starts, so that a sub-batch only ever waits for earlier ones) packs it, takes its box and brings it over; later sub-batches read
+// the owner's device copy instead of packing and uploading the scan again.
+struct cloud_entry {
+    std::atomic<int> box_ready{0};    // lo / hi / bad are valid
+    std::atomic<int> resident{0};     // dev / ev are valid: the owner's key kernel has been enqueued
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool bad = false;                 // non-finite coordinates
+    const float* dev = nullptr;       // packed coordinates inside the owner's device block
+    hipEvent_t ev = nullptr;          // recorded behind the owner's key kernel
+    hipStream_t ev_stream = nullptr;
+    int owner = -1;                   // sub-batch
+    bool shared_later = false;        // some later sub-batch reads it
+};
+// what a batch call works on: the scans, the pairs as rows of the scan table, their initial transforms
+struct batch_call {
+    const pcr_cloud_ref* clouds = nullptr;
+    int64_t n_clouds = 0;
+    const pcr_pair_ref* pairs = nullptr;
+    int64_t n_pairs = 0;
+    std::unique_ptr<cloud_entry[]> cache;
+    // device blocks whose contents later sub-batches read: released when the call ends (ctx, pointer, bytes)
+    std::mutex keep_mu;
+    struct kept { pcr_ctx* ctx; void* p; size_t bytes; };
+    std::vector<kept> keep;
+    const double* T0_of(int64_t i) const { return pairs[i].T0; }
+};
+
 // the per-pair path (what pcr_icp_batch did for every pair before the fused stages; still used for what they cannot take)
-int run_one_pair(pcr_ctx* ctx, const pcr_pair& P, const pcr_icp_params* params, pcr_icp_result* res) {
+int run_one_pair(pcr_ctx* ctx, const batch_call& call, int64_t i, const pcr_icp_params* params, pcr_icp_result* res) {
     static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const pcr_pair_ref& R = call.pairs[i];
+    if (R.src < 0 || R.src >= call.n_clouds || R.tgt < 0 || R.tgt >= call.n_clouds) return PCR_E_INVALID;
+    const pcr_cloud_ref &S = call.clouds[R.src], &T = call.clouds[R.tgt];
     pcr_cloud *src = nullptr, *tgt = nullptr;
     pcr_index* index = nullptr;
-    int rc = pcr_cloud_upload_f32(ctx, P.src, P.n_src, P.stride_src, &src);
-    if (rc == PCR_OK) rc = pcr_cloud_upload_f32(ctx, P.tgt, P.n_tgt, P.stride_tgt, &tgt);
+    int rc = pcr_cloud_upload_f32(ctx, S.xyz, S.n, S.stride, &src);
+    if (rc == PCR_OK) rc = pcr_cloud_upload_f32(ctx, T.xyz, T.n, T.stride, &tgt);
     if (rc == PCR_OK) rc = pcr_index_build(ctx, tgt, PCR_INDEX_GRID, 0.0, &index);
-    if (rc == PCR_OK) rc = pcr_icp(ctx, src, index, params, P.T0 ? P.T0 : eye, res);
+    if (rc == PCR_OK) rc = pcr_icp(ctx, src, index, params, R.T0 ? R.T0 : eye, res);
     if (index) pcr_index_free(ctx, index);
     if (tgt) pcr_cloud_free(ctx, tgt);
     if (src) pcr_cloud_free(ctx, src);
@@ -386,8 +425,11 @@ int ensure_pinned(pcr_ctx* ctx, size_t bytes) {
 // (PCR_E_UNSUPPORTED as a private "not taken" mark) or that are invalid; results/status of the others are final after end().
 struct batch_job {
     pcr_ctx* ctx;
-    const pcr_pair* pairs = nullptr;
+    batch_call* call = nullptr;
+    int index = 0;                 // which sub-batch of the call
     std::vector<int64_t> ids;
+    std::vector<char> room;        // per slot: it has room in the staging block (see layout())
+    std::vector<int> alias;        // per slot: -1 = this slot packs its scan; >= 0: the slot of this sub-batch that does; -2: an earlier sub-batch's copy
     int m = 0;
     const pcr_icp_params* params = nullptr;
     pcr_icp_result* results = nullptr;
@@ -403,6 +445,8 @@ struct batch_job {
     unsigned long long slots = 0, src_slots = 0;
     size_t xyz_bytes = 0, off_cl = 0, off_tg = 0, off_T0 = 0;
     bool nothing = false;          // layout() found nothing for the fused stages
+    bool keep_in = false;          // later sub-batches read this one's device copy of the coordinates: it outlives release()
+    hipEvent_t own_event = nullptr;
     char *hp = nullptr, *hp_dev = nullptr;
     size_t off_st = 0, off_plan = 0;
     pcr_batch_pass_args a{};
@@ -415,6 +459,13 @@ struct batch_job {
         : ctx(c), d_in(c), d_pts(c), d_keys(c), d_keys2(c), d_vals(c), d_vals2(c), d_tmp(c), d_cells(c), d_blocks(c), d_small(c), d_res(c), d_prev(c), d_cost(c),
           d_items(c), d_acc(c), d_st(c), d_tp(c) {}
     void release() {   // scratch back to the arena (stream-ordered with what was enqueued)
+        if (keep_in && d_in.p) {   // (the call releases it when every sub-batch is done)
+            std::lock_guard<std::mutex> g(call->keep_mu);
+            call->keep.push_back({ctx, d_in.p, d_in.bytes});
+            d_in.p = nullptr;
+            d_in.bytes = 0;
+            keep_in = false;
+        }
         for (dev_block* b : {&d_in, &d_pts, &d_keys, &d_keys2, &d_vals, &d_vals2, &d_tmp, &d_cells, &d_blocks, &d_small, &d_res, &d_prev, &d_cost, &d_items, &d_acc, &d_st, &d_tp}) b->free_now();
         active = false;
     }
@@ -423,22 +474,22 @@ struct batch_job {
         return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(y - x).count();
     }
     // begin() = layout() -> pack_cloud(c) for every cloud c in [0, 2m) (any thread, in any order) -> launch()
-    int layout(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_, batch_timing* tm_);
+    int layout(batch_call* call_, int index_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_, batch_timing* tm_);
     void pack_cloud(int c);
     int launch();
-    int begin(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_, batch_timing* tm_) {
-        int rc = layout(pairs_, ids_, m_, params_, results_, status_, tm_);
-        if (rc || nothing) return rc;
-        for (int c = 0; c < n_clouds; ++c) pack_cloud(c);
-        return launch();
+    const pcr_cloud_ref* ref_of(int c) const {   // scan of slot c (nullptr: the pair names no valid scan)
+        const pcr_pair_ref& R = call->pairs[ids[c % m]];
+        const int64_t g = c < m ? R.src : R.tgt;
+        return (g >= 0 && g < call->n_clouds) ? &call->clouds[g] : nullptr;
     }
+    int64_t scan_of(int c) const { const pcr_pair_ref& R = call->pairs[ids[c % m]]; return c < m ? R.src : R.tgt; }
     int enqueue_chunk();
     int end();
 };
 
-int batch_job::layout(const pcr_pair* pairs_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_,
+int batch_job::layout(batch_call* call_, int index_, const int64_t* ids_, int m_, const pcr_icp_params* params_, pcr_icp_result* results_, int32_t* status_,
                       batch_timing* tm_) {
-    pairs = pairs_; m = m_; params = params_; results = results_; status = status_; tm = tm_;
+    call = call_; index = index_; m = m_; params = params_; results = results_; status = status_; tm = tm_;
     ids.assign(ids_, ids_ + m_);
     active = false;
     nothing = false;
@@ -452,22 +503,46 @@ int batch_job::layout(const pcr_pair* pairs_, const int64_t* ids_, int m_, const
     bad_cloud.assign(n_clouds, 0);
     hi_all.assign(3 * (size_t)n_clouds, 0.0);
     slots = 0;
-    for (int half = 0; half < 2; ++half)
-        for (int k = 0; k < m; ++k) {
-            const pcr_pair& P = pairs[ids[k]];
-            const int64_t n = half == 0 ? P.n_src : P.n_tgt, stride = half == 0 ? P.stride_src : P.stride_tgt;
-            const float* ptr = half == 0 ? P.src : P.tgt;
-            if (n <= 0 || stride < 3 || !ptr || n > (1 << 24)) take[k] = 0;   // empty / invalid / very large clouds: per-pair path decides
+    auto usable = [&](int c) {
+        const pcr_cloud_ref* R = ref_of(c);
+        return R && R->n > 0 && R->stride >= 3 && R->xyz && R->n <= (1 << 24);
+    };
+    for (int c = 0; c < n_clouds; ++c)
+        if (!usable(c)) take[c % m] = 0;   // empty / invalid / very large clouds: per-pair path decides
+    // Who packs a slot's scan: an earlier sub-batch (the scan's owner: alias -2), another slot of this one (alias = that slot), or
+    // the slot itself (alias -1).  A slot has ROOM in the staging block when its pair is taken -- or when it is the one that must bring
+    // a scan over for later sub-batches although its own pair is not (room, but no points in the fused stages).
+    alias.assign(n_clouds, -1);
+    room.assign(n_clouds, 0);
+    {
+        std::vector<std::pair<int64_t, int>> packer;   // (scan, slot) of this sub-batch's packers
+        auto find = [&](int64_t g) { for (auto& e : packer) if (e.first == g) return e.second; return -1; };
+        for (int c = 0; c < n_clouds; ++c) {
+            if (!take[c % m]) continue;
+            room[c] = 1;
+            const int64_t g = scan_of(c);
+            if (call->cache[g].owner != index) { alias[c] = -2; continue; }
+            const int d = find(g);
+            if (d >= 0) alias[c] = d;
+            else packer.emplace_back(g, c);
         }
-    for (int half = 0; half < 2; ++half)
-        for (int k = 0; k < m; ++k) {
-            const pcr_pair& P = pairs[ids[k]];
-            const int64_t n = take[k] ? (half == 0 ? P.n_src : P.n_tgt) : 0;
-            batch_cloud& C = cl[half * m + k];
-            C.off = slots;
-            C.n = n;
-            slots += (unsigned long long)((n + SLOT - 1) / SLOT) * SLOT;
+        for (int c = 0; c < n_clouds; ++c) {
+            if (take[c % m] || !usable(c)) continue;
+            const int64_t g = scan_of(c);
+            const cloud_entry& E = call->cache[g];
+            if (E.owner != index || !E.shared_later || find(g) >= 0) continue;
+            room[c] = 1;
+            packer.emplace_back(g, c);
         }
+    }
+    for (int c = 0; c < n_clouds; ++c) {
+        batch_cloud& C = cl[c];
+        C.off = slots;
+        C.n = take[c % m] ? ref_of(c)->n : 0;
+        C.n_copy = room[c] ? ref_of(c)->n : 0;
+        C.src = nullptr;
+        slots += (unsigned long long)((C.n_copy + SLOT - 1) / SLOT) * SLOT;
+    }
     src_slots = cl[m].off;
     if (slots == 0 || slots >= (1ull << 31)) {
         for (int k = 0; k < m; ++k) status[ids[k]] = PCR_E_UNSUPPORTED;
@@ -488,18 +563,17 @@ int batch_job::layout(const pcr_pair* pairs_, const int64_t* ids_, int m_, const
     return PCR_OK;
 }
 
-// xyz columns of cloud c -> the staging block, its exact box on the way (float -> double is exact: the box the per-pair path takes)
+// xyz columns of cloud c -> the staging block, its exact box on the way (float -> double is exact: the box the per-pair path takes).
+// Only the slot that owns the scan packs it; the box goes to the call's table, where every other use of the scan finds it.
 void batch_job::pack_cloud(int c) {
     float* const h_xyz = (float*)hp;
-    {
-        const int k = c % m;
-        if (!take[k]) return;
-        const pcr_pair& P = pairs[ids[k]];
-        const bool is_src = c < m;
-        const int64_t n = is_src ? P.n_src : P.n_tgt, stride = is_src ? P.stride_src : P.stride_tgt;
-        const float* ptr = is_src ? P.src : P.tgt;
-        batch_cloud& C = cl[c];
-        float* dst = h_xyz + 3 * C.off;
+    if (!room[c]) return;
+    cloud_entry& E = call->cache[scan_of(c)];
+    if (alias[c] == -1) {
+        const pcr_cloud_ref& R = *ref_of(c);
+        const int64_t n = R.n, stride = R.stride;
+        const float* ptr = R.xyz;
+        float* dst = h_xyz + 3 * cl[c].off;
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         bool finite = true;
         for (int64_t i = 0; i < n; ++i) {   // (float -> double is exact: the box equals the one the per-pair path takes in binary64)
@@ -511,9 +585,15 @@ void batch_job::pack_cloud(int c) {
             lo[1] = y < lo[1] ? y : lo[1]; hi[1] = y > hi[1] ? y : hi[1];
             lo[2] = z < lo[2] ? z : lo[2]; hi[2] = z > hi[2] ? z : hi[2];
         }
-        if (!finite) { bad_cloud[c] = 1; return; }   // (the per-pair path reports it)
-        for (int a = 0; a < 3; ++a) { C.lo[a] = (double)lo[a]; hi_all[3 * (size_t)c + a] = (double)hi[a]; }
+        for (int a = 0; a < 3; ++a) { E.lo[a] = lo[a]; E.hi[a] = hi[a]; }
+        E.bad = !finite;
+        E.box_ready.store(1, std::memory_order_release);
+    } else {
+        // packed by another slot (this sub-batch's or an earlier one's, whose packing tasks were handed out before this one)
+        while (!E.box_ready.load(std::memory_order_acquire)) std::this_thread::yield();
     }
+    if (E.bad) { bad_cloud[c] = 1; return; }   // (the per-pair path reports it)
+    for (int a = 0; a < 3; ++a) { cl[c].lo[a] = (double)E.lo[a]; hi_all[3 * (size_t)c + a] = (double)E.hi[a]; }
 }
 
 int batch_job::launch() {
@@ -556,7 +636,7 @@ int batch_job::launch() {
     for (int k = 0; k < m; ++k) {
         if (!take[k]) {
             status[ids[k]] = PCR_E_UNSUPPORTED;
-            cl[k].n = 0;       // (its slots stay, empty: no tile of it does anything)
+            cl[k].n = 0;       // (its slots stay, empty: no tile of it does anything; a shared scan is still brought over: n_copy)
             cl[m + k].n = 0;
             tg[k].levels = 0;
             tg[k].cell = 1.0; tg[k].scale = tg[k].inv_scale = 1.0;
@@ -564,8 +644,11 @@ int batch_job::launch() {
             cl[k].inv = cl[m + k].inv = 1.0;
         } else any = true;
     }
-    if (!any || mbits + cbits > 63) {
+    bool must_upload = false;   // a scan later sub-batches wait for is brought over even when no pair of this sub-batch is taken
+    for (int c = 0; c < n_clouds; ++c) must_upload = must_upload || (room[c] && alias[c] == -1 && call->cache[scan_of(c)].shared_later);
+    if ((!any && !must_upload) || mbits + cbits > 63) {
         for (int k = 0; k < m; ++k) status[ids[k]] = PCR_E_UNSUPPORTED;
+        if (must_upload) return PCR_E_UNSUPPORTED;   // (cannot happen: mbits + cbits <= 63 for clouds of <= 2^24 points in <= 1024 slots)
         return PCR_OK;
     }
     // table pools: rigorous upper bounds of what the plan kernel will hand out (cells of level l <= min(n, cells of the box))
@@ -585,10 +668,9 @@ int batch_job::launch() {
             block_pool_slots += bcap < MIN_CAP ? MIN_CAP : bcap;
         }
     }
-    memcpy(hp + off_cl, cl.data(), sizeof(batch_cloud) * n_clouds);
     memcpy(hp + off_tg, tg.data(), sizeof(batch_target) * m);
     double* const h_T0 = (double*)(hp + off_T0);
-    for (int k = 0; k < m; ++k) memcpy(h_T0 + 16 * (size_t)k, pairs[ids[k]].T0 ? pairs[ids[k]].T0 : eye, 128);
+    for (int k = 0; k < m; ++k) memcpy(h_T0 + 16 * (size_t)k, call->pairs[ids[k]].T0 ? call->pairs[ids[k]].T0 : eye, 128);
     t_staged = t_packed;
     // ---- device memory
     const unsigned int n_tiles = (unsigned int)(src_slots / 32);
@@ -628,16 +710,51 @@ int batch_job::launch() {
     // everything crosses PCIe through kernels that read / write the pinned, device-mapped staging block: no copy engine
     hp_dev = nullptr;
     PCR_HIP(ctx, hipHostGetDevicePointer((void**)&hp_dev, hp, 0));
+    static const bool use_dma = getenv("PCR_BATCH_DMA") != nullptr;   // A/B: the packed coordinates by the copy engine instead
+    // where the key kernel finds every slot's coordinates: this sub-batch's staging block, or -- a scan an earlier sub-batch of the
+    // call owns -- that sub-batch's device copy, behind its key kernel (an event on its stream; its launch is waited for here: the
+    // owner is always an EARLIER sub-batch, whose tasks were handed out before this one's, so the wait cannot form a cycle)
+    bool owns_shared = false;
+    for (int c = 0; c < n_clouds; ++c) {
+        if (!room[c]) continue;
+        const float* const own_base = use_dma ? d_in.as<float>() : (const float*)hp_dev;
+        if (alias[c] == -1) { cl[c].src = own_base + 3 * cl[c].off; owns_shared = owns_shared || call->cache[scan_of(c)].shared_later; }
+        else if (alias[c] >= 0) cl[c].src = own_base + 3 * cl[alias[c]].off;
+        else if (!take[c % m]) cl[c].n_copy = 0;   // (un-taken since the lay-out, and somebody else's scan: nothing to bring over)
+        else {
+            cloud_entry& E = call->cache[scan_of(c)];
+            while (!E.resident.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (E.ev_stream != st) PCR_HIP(ctx, hipStreamWaitEvent(st, E.ev, 0));
+            cl[c].src = E.dev;
+        }
+    }
+    memcpy(hp + off_cl, cl.data(), sizeof(batch_cloud) * n_clouds);
     hipLaunchKernelGGL(batch_words_kernel, dim3(8), dim3(256), 0, st, (const unsigned long long*)(hp_dev + off_cl), (unsigned long long*)ds,
                        (unsigned long long)(s_in_end / 8), (unsigned long long)((s_plan + 256) / 8));   // descriptors; counts, offsets and plan zeroed
     const unsigned int blocks_all = (unsigned int)(slots / SLOT), blocks_src = (unsigned int)(src_slots / SLOT), blocks_tgt = blocks_all - blocks_src;
-    static const bool use_dma = getenv("PCR_BATCH_DMA") != nullptr;   // A/B: the packed coordinates by the copy engine instead
     if (use_dma) PCR_HIP(ctx, hipMemcpyAsync(d_in.p, h_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
     static const int keys_blocks_env = getenv("PCR_BATCH_KEYS_BLOCKS") ? atoi(getenv("PCR_BATCH_KEYS_BLOCKS")) : 0;
     unsigned int keys_grid = keys_blocks_env > 0 ? (unsigned int)keys_blocks_env : 64u;   // (256 pairs, ms per batch: one block per 256 records 6.4-6.8, 1024 blocks 6.1-6.3, 128: 5.9, 64: 5.4, 32: 5.7, 16: 5.9-6.2)
     if (keys_grid > blocks_all) keys_grid = blocks_all;
-    hipLaunchKernelGGL(batch_keys_kernel, dim3(keys_grid), dim3(SLOT), 0, st, use_dma ? d_in.as<float>() : (const float*)hp_dev, d_in.as<float>(), d_cl, n_clouds,
+    hipLaunchKernelGGL(batch_keys_kernel, dim3(keys_grid), dim3(SLOT), 0, st, d_in.as<float>(), d_cl, n_clouds,
                        mbits, blocks_all, d_keys.as<unsigned long long>(), d_vals.as<unsigned int>());
+    if (owns_shared) {
+        // later sub-batches read this one's device copy of the scans they share with it
+        hipEvent_t ev = nullptr;
+        PCR_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        PCR_HIP(ctx, hipEventRecord(ev, st));
+        own_event = ev;
+        keep_in = true;
+        for (int c = 0; c < n_clouds; ++c) {
+            if (!room[c] || alias[c] != -1) continue;
+            cloud_entry& E = call->cache[scan_of(c)];
+            if (!E.shared_later) continue;
+            E.dev = d_in.as<float>() + 3 * cl[c].off;
+            E.ev = ev;
+            E.ev_stream = st;
+            E.resident.store(1, std::memory_order_release);
+        }
+    }
     // (rocPRIM's default configuration = merge sort at this size.  Onesweep is faster for one sort of 1.3 M pairs alone -- 126 against
     // 190 us -- but not with eight sub-batches' sorts in flight together, and it adds a dozen 17-us fills per sort.)
     PCR_HIP(ctx, rocprim::radix_sort_pairs(d_tmp.p, temp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned int>(),
@@ -770,15 +887,22 @@ int batch_job::end() {
     return PCR_OK;
 }
 
-}  // namespace
+// threads of a batch call: created one by one, so that a refused thread (EAGAIN under a process limit) degrades the pool instead of
+// letting std::system_error escape through the C ABI; with none, the caller runs the work itself
+template <typename F>
+void run_pool(int n_workers, F&& worker) {
+    std::vector<std::thread> pool;
+    for (int c = 1; c < n_workers; ++c) {
+        try { pool.emplace_back(worker); }
+        catch (...) { break; }
+    }
+    worker();
+    for (auto& t : pool) t.join();
+}
 
-extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_t n_pairs, const pcr_icp_params* params,
-                             pcr_icp_result* results, int32_t* status_out) {
-    if (!ctxs || n_ctx <= 0 || (n_pairs > 0 && (!pairs || !results)) || !params) return PCR_E_INVALID;
-    for (int c = 0; c < n_ctx; ++c)
-        if (!ctxs[c]) return PCR_E_INVALID;
-    if (params->max_iter > PCR_ICP_MAX_LOG) return PCR_E_TOO_MANY_ITERS;
-    if (n_pairs == 0) return PCR_OK;
+// the fused batch (or, with PCR_BATCH_PER_PAIR=1 / ungated runs, the per-pair path) over the call's pairs
+int batch_run(pcr_ctx* const* ctxs, int n_ctx, batch_call& call, const pcr_icp_params* params, pcr_icp_result* results, int32_t* status_out) {
+    const int64_t n_pairs = call.n_pairs;
     // several worker contexts keep the device busy together: two-launch ICP passes for what takes the per-pair path
     int was_shared[64];
     for (int c = 0; c < n_ctx && c < 64; ++c) {
@@ -825,7 +949,7 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
         for (int64_t i = lo; i < hi; ++i) {
             if (status[i] != PCR_E_UNSUPPORTED) continue;
             memset(&results[i], 0, sizeof(results[i]));
-            status[i] = run_one_pair(ctx, pairs[i], params, &results[i]);
+            status[i] = run_one_pair(ctx, call, i, params, &results[i]);
             note_error(status[i]);
         }
         if (timing) tm.ns[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
@@ -833,7 +957,9 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
     for (int64_t i = 0; i < n_pairs; ++i) status[i] = PCR_E_UNSUPPORTED;
     if (!fused) {   // per-pair path: a pool of workers, one context each, pairs from a shared counter
         std::atomic<int64_t> next(0);
-        auto worker = [&](pcr_ctx* ctx) {
+        std::atomic<int> next_ctx(0);
+        auto worker = [&]() {
+            pcr_ctx* ctx = ctxs[next_ctx.fetch_add(1)];
             hipSetDevice(ctx->device);
             for (;;) {
                 const int64_t i = next.fetch_add(1);
@@ -841,14 +967,18 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
                 per_pair_rest(ctx, i, i + 1);
             }
         };
-        const int n_workers = (int)(n_pairs < n_ctx ? n_pairs : n_ctx);
-        if (n_workers <= 1) worker(ctxs[0]);
-        else {
-            std::vector<std::thread> pool;
-            for (int c = 0; c < n_workers; ++c) pool.emplace_back(worker, ctxs[c]);
-            for (auto& t : pool) t.join();
-        }
+        run_pool((int)(n_pairs < n_ctx ? n_pairs : n_ctx), worker);
     } else {
+        // every scan's owner = the first sub-batch that uses it; shared_later = some other sub-batch uses it too
+        for (int64_t j = 0; j < n_sub; ++j)
+            for (int64_t i = bounds[(size_t)j]; i < bounds[(size_t)j + 1]; ++i)
+                for (int h = 0; h < 2; ++h) {
+                    const int64_t g = h == 0 ? call.pairs[i].src : call.pairs[i].tgt;
+                    if (g < 0 || g >= call.n_clouds) continue;
+                    cloud_entry& E = call.cache[g];
+                    if (E.owner < 0) E.owner = (int)j;
+                    else if (E.owner != (int)j) E.shared_later = true;
+                }
         struct sub_state {
             std::unique_ptr<batch_job> job;
             int64_t lo = 0, hi = 0;
@@ -881,7 +1011,7 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
                 std::call_once(S.once, [&] {
                     if (j >= n_ctx)   // the context (stream, staging block, arena) is still the earlier sub-batch's until that one has finished
                         while (!subs[(size_t)(j - n_ctx)].finished.load(std::memory_order_acquire)) std::this_thread::yield();
-                    S.rc = J.layout(pairs, S.ids.data(), (int)S.ids.size(), params, results, status, timing ? &tm : nullptr);
+                    S.rc = J.layout(&call, (int)j, S.ids.data(), (int)S.ids.size(), params, results, status, timing ? &tm : nullptr);
                 });
                 const bool usable = S.rc == PCR_OK && !J.nothing;
                 if (usable) J.pack_cloud(c);
@@ -910,12 +1040,12 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
         if (n_workers < 1) n_workers = 1;
         if (n_workers > 64) n_workers = 64;
         if ((int64_t)n_workers > n_tasks) n_workers = (int)n_tasks;
-        if (n_workers <= 1) worker();
-        else {
-            std::vector<std::thread> pool;
-            for (int c = 0; c < n_workers; ++c) pool.emplace_back(worker);
-            for (auto& t : pool) t.join();
-        }
+        run_pool(n_workers, worker);
+        // what later sub-batches read of earlier ones: back to the arenas now that every stream has been waited for
+        for (auto& S : subs)
+            if (S.job && S.job->own_event) hipEventDestroy(S.job->own_event);
+        for (auto& k : call.keep) pcr_dev_free(k.ctx, k.p, k.bytes);
+        call.keep.clear();
     }
     for (int c = 0; c < n_ctx && c < 64; ++c) ctxs[c]->shared_device = was_shared[c];
     if (timing)
@@ -925,4 +1055,169 @@ extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pa
                 tm.ns[5] ? tm.ns[0] / 1e3 / tm.ns[5] : 0.0, tm.ns[5] ? tm.ns[1] / 1e3 / tm.ns[5] : 0.0, tm.ns[5] ? tm.ns[2] / 1e3 / tm.ns[5] : 0.0,
                 tm.ns[5] ? tm.ns[3] / 1e3 / tm.ns[5] : 0.0, tm.ns[4] / 1e3);
     return hard_error.load();
+}
+
+int check_batch_args(pcr_ctx* const* ctxs, int n_ctx, const pcr_icp_params* params) {
+    if (!ctxs || n_ctx <= 0 || !params) return PCR_E_INVALID;
+    for (int c = 0; c < n_ctx; ++c)
+        if (!ctxs[c]) return PCR_E_INVALID;
+    if (params->max_iter > PCR_ICP_MAX_LOG) return PCR_E_TOO_MANY_ITERS;
+    return PCR_OK;
+}
+
+}  // namespace
+
+extern "C" int pcr_icp_batch(pcr_ctx* const* ctxs, int n_ctx, const pcr_pair* pairs, int64_t n_pairs, const pcr_icp_params* params,
+                             pcr_icp_result* results, int32_t* status_out) {
+    int rc = check_batch_args(ctxs, n_ctx, params);
+    if (rc) return rc;
+    if (n_pairs > 0 && (!pairs || !results)) return PCR_E_INVALID;
+    if (n_pairs == 0) return PCR_OK;
+    // the scan table of the call: host buffers that are the same (pointer, size, stride) are the same scan
+    std::vector<pcr_cloud_ref> clouds;
+    std::vector<pcr_pair_ref> refs((size_t)n_pairs);
+    try {
+        clouds.reserve((size_t)(2 * n_pairs));
+        struct key { const float* p; int64_t n, s; };
+        std::vector<std::pair<key, int>> table;   // open addressing by pointer hash
+        size_t cap = 64;
+        while (cap < (size_t)(4 * n_pairs)) cap <<= 1;
+        table.assign(cap, {key{nullptr, 0, 0}, -1});
+        auto scan = [&](const float* p, int64_t n, int64_t st) -> int {
+            size_t h = ((size_t)(uintptr_t)p >> 4) * 0x9E3779B97F4A7C15ull;
+            h ^= (size_t)n * 0xD1B54A32D192ED03ull + (size_t)st;
+            for (size_t i = h & (cap - 1);; i = (i + 1) & (cap - 1)) {
+                auto& e = table[i];
+                if (e.second < 0) {
+                    e.first = key{p, n, st};
+                    e.second = (int)clouds.size();
+                    clouds.push_back(pcr_cloud_ref{p, n, st});
+                    return e.second;
+                }
+                if (e.first.p == p && e.first.n == n && e.first.s == st) return e.second;
+            }
+        };
+        for (int64_t i = 0; i < n_pairs; ++i) {
+            refs[(size_t)i].src = scan(pairs[i].src, pairs[i].n_src, pairs[i].stride_src);
+            refs[(size_t)i].tgt = scan(pairs[i].tgt, pairs[i].n_tgt, pairs[i].stride_tgt);
+            refs[(size_t)i].T0 = pairs[i].T0;
+        }
+    } catch (...) { return PCR_E_NOMEM; }
+    batch_call call;
+    call.clouds = clouds.data();
+    call.n_clouds = (int64_t)clouds.size();
+    call.pairs = refs.data();
+    call.n_pairs = n_pairs;
+    call.cache.reset(new (std::nothrow) cloud_entry[clouds.size()]);
+    if (!call.cache) return PCR_E_NOMEM;
+    return batch_run(ctxs, n_ctx, call, params, results, status_out);
+}
+
+extern "C" int pcr_global_default_params(double voxel_size, pcr_global_params* p) {
+    if (!p || !(voxel_size > 0)) return PCR_E_INVALID;
+    memset(p, 0, sizeof(*p));
+    p->voxel_size = voxel_size;                 // main.py:196
+    p->normal_radius = voxel_size * 2;          // main.py:38
+    p->fpfh_radius = voxel_size * 5;            // main.py:43
+    p->normal_max_nn = 30;                      // main.py:40
+    p->fpfh_max_nn = 100;                       // main.py:46
+    p->mutual_filter = 1;                       // main.py:74
+    pcr_ransac_default_params(&p->ransac);
+    p->ransac.max_distance = voxel_size * 1.5;  // main.py:70
+    return PCR_OK;
+}
+
+// The pair loop of Registration/main.py:183-216 over a table of scans (see pcr.h).
+extern "C" int pcr_register_pairs(pcr_ctx* const* ctxs, int n_ctx, const pcr_cloud_ref* clouds, int64_t n_clouds, const pcr_pair_ref* pairs, int64_t n_pairs,
+                                  const pcr_global_params* global, const pcr_icp_params* icp, pcr_icp_result* results, int32_t* status_out, double* T_init_out) {
+    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int rc = check_batch_args(ctxs, n_ctx, icp);
+    if (rc) return rc;
+    if (n_pairs > 0 && (!pairs || !results || !clouds)) return PCR_E_INVALID;
+    if (n_pairs == 0) return PCR_OK;
+    for (int64_t i = 0; i < n_pairs; ++i)
+        if (pairs[i].src < 0 || pairs[i].src >= n_clouds || pairs[i].tgt < 0 || pairs[i].tgt >= n_clouds) return PCR_E_INVALID;
+    std::vector<pcr_pair_ref> refs;
+    std::vector<double> T_init;
+    try {
+        refs.assign(pairs, pairs + n_pairs);
+        T_init.assign((size_t)n_pairs * 16, 0.0);
+    } catch (...) { return PCR_E_NOMEM; }
+    for (int64_t i = 0; i < n_pairs; ++i) memcpy(&T_init[(size_t)i * 16], pairs[i].T0 ? pairs[i].T0 : eye, 128);
+    std::atomic<int> hard_error(PCR_OK);
+    // (a scan the stage cannot take -- PCR_E_EMPTY, PCR_E_UNSUPPORTED -- leaves its pairs at identity; anything else negative ends the call)
+    auto note_error = [&](int e) { if (e < 0 && e != PCR_E_EMPTY && e != PCR_E_UNSUPPORTED) { int expected = PCR_OK; hard_error.compare_exchange_strong(expected, e); } };
+    if (global) {
+        // ---- prepare_dataset (main.py:197): every scan that a pair without a given T0 uses is preprocessed ONCE, on whichever
+        // context's thread gets to it; the descriptors stay on the device for every pair the scan takes part in
+        std::vector<char> need((size_t)n_clouds, 0);
+        std::vector<int64_t> todo, todo_pairs;
+        for (int64_t i = 0; i < n_pairs; ++i)
+            if (!pairs[i].T0) { need[(size_t)pairs[i].src] = 1; need[(size_t)pairs[i].tgt] = 1; todo_pairs.push_back(i); }
+        for (int64_t g = 0; g < n_clouds; ++g)
+            if (need[(size_t)g]) todo.push_back(g);
+        struct prep_slot { pcr_prep* prep = nullptr; pcr_ctx* ctx = nullptr; int rc = PCR_OK; };
+        std::vector<prep_slot> preps((size_t)n_clouds);
+        {
+            std::atomic<int64_t> next(0);
+            std::atomic<int> next_ctx(0);
+            auto worker = [&]() {
+                pcr_ctx* ctx = ctxs[next_ctx.fetch_add(1)];
+                hipSetDevice(ctx->device);
+                for (;;) {
+                    const int64_t t = next.fetch_add(1);
+                    if (t >= (int64_t)todo.size()) break;
+                    const int64_t g = todo[(size_t)t];
+                    prep_slot& P = preps[(size_t)g];
+                    P.ctx = ctx;
+                    pcr_cloud* full = nullptr;
+                    P.rc = pcr_cloud_upload_f32(ctx, clouds[g].xyz, clouds[g].n, clouds[g].stride, &full);
+                    if (P.rc == PCR_OK)
+                        P.rc = pcr_preprocess(ctx, full, global->voxel_size, global->normal_radius, global->normal_max_nn, global->fpfh_radius, global->fpfh_max_nn, &P.prep);
+                    if (full) pcr_cloud_free(ctx, full);
+                }
+            };
+            run_pool((int)((int64_t)n_ctx < (int64_t)todo.size() ? n_ctx : (int)todo.size()), worker);
+        }
+        // ---- execute_global_registration (main.py:200) per pair: any context may read any scan's descriptors (same device, and
+        // every pcr_preprocess has synchronised before it returned)
+        {
+            std::atomic<int64_t> next(0);
+            std::atomic<int> next_ctx(0);
+            auto worker = [&]() {
+                pcr_ctx* ctx = ctxs[next_ctx.fetch_add(1)];
+                hipSetDevice(ctx->device);
+                for (;;) {
+                    const int64_t t = next.fetch_add(1);
+                    if (t >= (int64_t)todo_pairs.size()) break;
+                    const int64_t i = todo_pairs[(size_t)t];
+                    const prep_slot &S = preps[(size_t)pairs[i].src], &T = preps[(size_t)pairs[i].tgt];
+                    if (S.rc != PCR_OK || T.rc != PCR_OK || !S.prep || !T.prep) {
+                        // a scan the stage cannot take (empty, one voxel, ...): identity, like a pair without a valid hypothesis; hard errors are reported
+                        note_error(S.rc);
+                        note_error(T.rc);
+                        continue;
+                    }
+                    pcr_ransac_result rr;
+                    const int e = pcr_global_registration(ctx, S.prep, T.prep, &global->ransac, global->mutual_filter, &rr);
+                    note_error(e);
+                    if (e == PCR_OK) memcpy(&T_init[(size_t)i * 16], rr.T, 128);
+                }
+            };
+            run_pool((int)((int64_t)n_ctx < (int64_t)todo_pairs.size() ? n_ctx : (int)todo_pairs.size()), worker);
+        }
+        for (auto& P : preps)
+            if (P.prep) { hipSetDevice(P.ctx->device); pcr_prep_free(P.ctx, P.prep); }
+        for (int64_t i = 0; i < n_pairs; ++i) refs[(size_t)i].T0 = &T_init[(size_t)i * 16];
+    }
+    if (T_init_out) memcpy(T_init_out, T_init.data(), sizeof(double) * 16 * (size_t)n_pairs);
+    if (hard_error.load() < 0) return hard_error.load();
+    batch_call call;
+    call.clouds = clouds;
+    call.n_clouds = n_clouds;
+    call.pairs = refs.data();
+    call.n_pairs = n_pairs;
+    call.cache.reset(new (std::nothrow) cloud_entry[(size_t)n_clouds]);
+    if (!call.cache) return PCR_E_NOMEM;
+    return batch_run(ctxs, n_ctx, call, icp, results, status_out);
 }

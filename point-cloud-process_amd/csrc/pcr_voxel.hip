@@ -94,7 +94,17 @@ __device__ static sum3 pw_leaf8(const coord_view& a, unsigned int off, unsigned 
     }
     vox_xyz r = a.at(off + lane8);
     unsigned int i = 8;
-    for (; i < n - (n % 8); i += 8) {
+    const unsigned int lim = n - (n % 8);
+    // four steps' records requested together (a leaf is <= 16 steps: one dependent memory round trip per step was the leaf's
+    // whole time); the additions stay in NumPy's order
+    for (; i + 32 <= lim; i += 32) {
+        const vox_xyz p0 = a.at(off + i + lane8), p1 = a.at(off + i + 8 + lane8), p2 = a.at(off + i + 16 + lane8), p3 = a.at(off + i + 24 + lane8);
+        r.x += p0.x; r.y += p0.y; r.z += p0.z;
+        r.x += p1.x; r.y += p1.y; r.z += p1.z;
+        r.x += p2.x; r.y += p2.y; r.z += p2.z;
+        r.x += p3.x; r.y += p3.y; r.z += p3.z;
+    }
+    for (; i < lim; i += 8) {
         const vox_xyz p = a.at(off + i + lane8);
         r.x += p.x; r.y += p.y; r.z += p.z;
     }
@@ -117,11 +127,11 @@ __device__ static sum3 pw_leaf8(const coord_view& a, unsigned int off, unsigned 
 // and a kernel that uses scratch pays for it at its first dispatch after kernels that do not.
 struct pw_frame { unsigned int off, n; int state; int pad; sum3 left; };
 constexpr int PW_DEPTH = 28;   // n < 2^32 halves to <= 128 in 25 steps
-__device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int n, int lane8, pw_frame* st) {
-    if (n <= 128) return pw_leaf8(a, 0, n, lane8);
+__device__ static sum3 numpy_pairwise_sum(const coord_view& a, unsigned int off0, unsigned int n, int lane8, pw_frame* st) {
+    if (n <= 128) return pw_leaf8(a, off0, n, lane8);
     // explicit stack for: sum(off, n) = n <= 128 ? leaf : sum(off, n2) + sum(off + n2, n - n2), n2 = (n/2) rounded down to 8
     int sp = 0;
-    if (lane8 == 0) st[0] = pw_frame{0u, n, 0, 0, {0.0, 0.0, 0.0}};
+    if (lane8 == 0) st[0] = pw_frame{off0, n, 0, 0, {0.0, 0.0, 0.0}};
     sp = 1;
     sum3 ret = {0.0, 0.0, 0.0};
     while (sp > 0) {
@@ -162,47 +172,25 @@ __device__ static inline unsigned long long splitmix64(unsigned long long x) {
 // Coordinates into voxel-major order, one thread per POINT: the random 32-byte reads through the permutation happen here, a
 // million of them in flight at once; the emit kernel then streams every voxel's run.  (One thread per voxel gathering its own
 // points through the permutation -- a chain of dependent scattered reads per thread -- took 132 us at 1 M points, 18 x the
-// algorithmic traffic.)
+// algorithmic traffic.)  Also zeroes the emit stage's list counter (stream-ordered in front of it).
 __global__ void __launch_bounds__(256)
-voxel_gather_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restrict__ perm, long long n, vox_xyz* __restrict__ out) {
+voxel_gather_kernel(const pcr_pt* __restrict__ pts, const unsigned int* __restrict__ perm, long long n, vox_xyz* __restrict__ out, unsigned int* __restrict__ big_count) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *big_count = 0u;
     if (i >= n) return;
     const pcr_pt p = pts[perm[i]];
     out[i] = vox_xyz{p.x, p.y, p.z};
 }
 
-// EIGHT LANES per emitted voxel v in [0, n_groups - 1): the last group is never emitted (modes 0, 1); mode 2 emits all
-__global__ void __launch_bounds__(256)
-voxel_emit_kernel(const vox_xyz* __restrict__ xyz, const unsigned int* __restrict__ heads, const unsigned int* __restrict__ n_groups_p, long long n, int mode,
-                  unsigned long long seed, pcr_pt* __restrict__ out_pts, double* __restrict__ out_xyz) {
-    __shared__ pw_frame s_stack[256 / 8][PW_DEPTH];
-    pw_frame* const st = s_stack[threadIdx.x >> 3];
-    const unsigned int ng = *n_groups_p;
-    const int lane8 = threadIdx.x & 7;
-    if (ng == 0) return;
-    const unsigned int n_emit = mode == 2 ? ng : ng - 1;   // (only known on the device: a fixed grid strides over the voxels)
-    for (unsigned int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; v < n_emit; v += (gridDim.x * blockDim.x) >> 3) {
-    const unsigned int s = heads[v], e = v + 1 < ng ? heads[v + 1] : (unsigned int)n;
-    const unsigned int cnt = e - s;
-    double ox, oy, oz;
-    if (mode == 2) {
-        // Open3D voxel_down_sample: running sum in input order, then one division
-        ox = oy = oz = 0.0;
-        for (unsigned int k = 0; k < cnt; ++k) {
-            const vox_xyz p = xyz[s + k];
-            ox += p.x; oy += p.y; oz += p.z;
-        }
-        ox /= (double)cnt; oy /= (double)cnt; oz /= (double)cnt;
-    } else if (mode == 0) {
-        const coord_view a{xyz + s};
-        const sum3 t = numpy_pairwise_sum(a, cnt, lane8, st);
-        ox = t.x / (double)cnt; oy = t.y / (double)cnt; oz = t.z / (double)cnt;
-    } else {
-        const unsigned int k = (unsigned int)(splitmix64(seed ^ ((unsigned long long)v * 0xD1B54A32D192ED03ull)) % cnt);
-        const vox_xyz p = xyz[s + k];
-        ox = p.x; oy = p.y; oz = p.z;
-    }
-    if (lane8 != 0) continue;
+// A populous voxel must not be walked by one lane group alone (2 m leaves on a scan: tens of thousands of points in the voxels
+// next to the sensor -- 0.7 ms of a 1.2 ms down-sample at 120 000 points, 2.4 ms at 1 M): the emit kernel appends voxels above
+// these sizes to a list and voxel_emit_big_kernel gives each of them a block (NumPy's pairwise recursion: independent subtrees)
+// or a wave (Open3D's running sum: an LDS-pipelined chain).
+constexpr unsigned int VOX_BIG_PAIRWISE = 1024;   // mode 0
+constexpr unsigned int VOX_BIG_RUNNING = 64;      // mode 2
+__host__ __device__ static inline unsigned int voxel_big_threshold(int mode) { return mode == 0 ? VOX_BIG_PAIRWISE : (mode == 2 ? VOX_BIG_RUNNING : 0xffffffffu); }
+
+__device__ static inline void voxel_store(unsigned int v, double ox, double oy, double oz, pcr_pt* __restrict__ out_pts, double* __restrict__ out_xyz) {
     if (out_pts) {
         pcr_pt o;
         o.x = ox; o.y = oy; o.z = oz;
@@ -214,6 +202,181 @@ voxel_emit_kernel(const vox_xyz* __restrict__ xyz, const unsigned int* __restric
         out_xyz[3 * (size_t)v + 1] = oy;
         out_xyz[3 * (size_t)v + 2] = oz;
     }
+}
+
+// EIGHT LANES per emitted voxel v in [0, n_groups - 1): the last group is never emitted (modes 0, 1); mode 2 emits all
+__global__ void __launch_bounds__(256)
+voxel_emit_kernel(const vox_xyz* __restrict__ xyz, const unsigned int* __restrict__ heads, const unsigned int* __restrict__ n_groups_p, long long n, int mode,
+                  unsigned long long seed, pcr_pt* __restrict__ out_pts, double* __restrict__ out_xyz, unsigned int* __restrict__ big_count,
+                  unsigned int* __restrict__ big_list) {
+    __shared__ pw_frame s_stack[256 / 8][PW_DEPTH];
+    pw_frame* const st = s_stack[threadIdx.x >> 3];
+    const unsigned int ng = *n_groups_p;
+    const int lane8 = threadIdx.x & 7;
+    if (ng == 0) return;
+    const unsigned int n_emit = mode == 2 ? ng : ng - 1;   // (only known on the device: a fixed grid strides over the voxels)
+    const unsigned int big = voxel_big_threshold(mode);
+    for (unsigned int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; v < n_emit; v += (gridDim.x * blockDim.x) >> 3) {
+    const unsigned int s = heads[v], e = v + 1 < ng ? heads[v + 1] : (unsigned int)n;
+    const unsigned int cnt = e - s;
+    if (cnt > big) {   // (group-uniform)
+        if (lane8 == 0) big_list[atomicAdd(big_count, 1u)] = v;
+        continue;
+    }
+    double ox, oy, oz;
+    if (mode == 2) {
+        // Open3D voxel_down_sample: running sum in input order, then one division.  The group's lanes fetch eight records at a
+        // time (one coalesced read) and every lane runs the same chain over them through the cross-lane network -- one lane
+        // fetching record after record paid a memory round trip per point.
+        ox = oy = oz = 0.0;
+        for (unsigned int k0 = 0; k0 < cnt; k0 += 8) {
+            vox_xyz p = vox_xyz{0.0, 0.0, 0.0};
+            if (k0 + lane8 < cnt) p = xyz[s + k0 + lane8];
+            const unsigned int m = cnt - k0 < 8u ? cnt - k0 : 8u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double px = __shfl(p.x, j, 8), py = __shfl(p.y, j, 8), pz = __shfl(p.z, j, 8);
+                if ((unsigned int)j < m) { ox += px; oy += py; oz += pz; }
+            }
+        }
+        ox /= (double)cnt; oy /= (double)cnt; oz /= (double)cnt;
+    } else if (mode == 0) {
+        const coord_view a{xyz + s};
+        const sum3 t = numpy_pairwise_sum(a, 0u, cnt, lane8, st);   // (cnt <= 1024: one inner-loop call of np.add.reduce, from the identity + 0.0)
+        ox = (0.0 + t.x) / (double)cnt; oy = (0.0 + t.y) / (double)cnt; oz = (0.0 + t.z) / (double)cnt;
+    } else {
+        const unsigned int k = (unsigned int)(splitmix64(seed ^ ((unsigned long long)v * 0xD1B54A32D192ED03ull)) % cnt);
+        const vox_xyz p = xyz[s + k];
+        ox = p.x; oy = p.y; oz = p.z;
+    }
+    if (lane8 != 0) continue;
+    voxel_store(v, ox, oy, oz, out_pts, out_xyz);
+    }
+}
+
+// The listed voxels.
+//   mode 0 (np.mean = NumPy's pairwise summation): one BLOCK per voxel.  np.add.reduce hands its inner loop at most
+//   np.getbufsize() = 8192 elements at a time: the result is (((0 + pw(a[0:8192])) + pw(a[8192:16384])) + ...), pw = the
+//   recursion below over one such chunk (checked against NumPy: a single recursion over the whole run differs from np.mean
+//   from 8193 elements on).  Within a chunk, the recursion sum(off, n) = sum(off, n2) + sum(off + n2, n - n2),
+//   n2 = (n / 2) rounded down to a multiple of 8, splits into 2^D independent subtrees as long as every node above them has more
+//   than 128 elements (the smallest node of a depth is its leftmost: n -> n2 is monotone); each of the block's 32 lane groups sums
+//   one subtree exactly as the single group would have, and the partial sums meet in the recursion's own tree order -- a balanced
+//   binary tree over the 2^D subtrees, left + right at every node -- so the result is bit for bit the sequential recursion's.
+//   mode 2 (Open3D's running sum in input order): one WAVE per voxel.  The chain of additions cannot be split, but it need not
+//   wait for memory: the wave copies chunks of 256 points into its LDS slice (coalesced, the next chunk in flight while the
+//   current one is summed) and lanes 0..2 run the x, y and z chains side by side from there.
+constexpr int VOX_RUN_CHUNK = 256;   // points per LDS chunk of the running sum (6 KB; two per wave)
+constexpr int VOX_SPLIT_DEPTH = 5;   // 2^5 = the block's 32 lane groups
+constexpr unsigned int NPY_BUFSIZE = 8192;   // np.getbufsize(): elements per inner-loop call of a NumPy reduction
+union voxel_big_lds {
+    struct { pw_frame stack[256 / 8][PW_DEPTH]; sum3 sub[1 << VOX_SPLIT_DEPTH]; } pw;
+    double run[4][2][3 * VOX_RUN_CHUNK];
+};
+__global__ void __launch_bounds__(256)
+voxel_emit_big_kernel(const vox_xyz* __restrict__ xyz, const unsigned int* __restrict__ heads, const unsigned int* __restrict__ n_groups_p, long long n, int mode,
+                      pcr_pt* __restrict__ out_pts, double* __restrict__ out_xyz, const unsigned int* __restrict__ big_count,
+                      const unsigned int* __restrict__ big_list) {
+    __shared__ voxel_big_lds L;
+    const unsigned int nb = *big_count, ng = *n_groups_p;
+    if (mode == 0) {
+        const int grp = threadIdx.x >> 3, lane8 = threadIdx.x & 7;
+        for (unsigned int b = blockIdx.x; b < nb; b += gridDim.x) {
+            const unsigned int v = big_list[b];
+            const unsigned int s = heads[v], e = v + 1 < ng ? heads[v + 1] : (unsigned int)n;
+            const unsigned int cnt = e - s;
+            const coord_view a{xyz + s};
+            sum3 S = {0.0, 0.0, 0.0};   // (thread 0) np.add.reduce: the running value starts at the identity + 0.0
+            for (unsigned int c0 = 0; c0 < cnt; c0 += NPY_BUFSIZE) {
+                const unsigned int clen = cnt - c0 < NPY_BUFSIZE ? cnt - c0 : NPY_BUFSIZE;
+                int D = 0;
+                for (unsigned int m = clen; D < VOX_SPLIT_DEPTH && m > 128u; ++D) m = (m / 2u) & ~7u;   // m = smallest node of depth D
+                // (the loop leaves D = number of levels whose nodes ALL split: the test looks at depth D's smallest node before going deeper)
+                if (grp < (1 << D)) {
+                    unsigned int off = c0, len = clen;
+                    for (int l = D - 1; l >= 0; --l) {
+                        const unsigned int n2 = (len / 2u) & ~7u;
+                        if ((grp >> l) & 1) { off += n2; len -= n2; }
+                        else len = n2;
+                    }
+                    const sum3 t = numpy_pairwise_sum(a, off, len, lane8, L.pw.stack[grp]);
+                    if (lane8 == 0) L.pw.sub[grp] = t;
+                }
+                __syncthreads();
+                for (int l = D - 1; l >= 0; --l) {   // level l: node i = node 2i + node 2i+1 of level l + 1
+                    sum3 t = {0.0, 0.0, 0.0};
+                    const bool act = threadIdx.x < (1u << l);
+                    if (act) {
+                        const sum3 a0 = L.pw.sub[2 * threadIdx.x], a1 = L.pw.sub[2 * threadIdx.x + 1];
+                        t.x = a0.x + a1.x; t.y = a0.y + a1.y; t.z = a0.z + a1.z;
+                    }
+                    __syncthreads();
+                    if (act) L.pw.sub[threadIdx.x] = t;
+                    __syncthreads();
+                }
+                if (threadIdx.x == 0) {
+                    const sum3 t = L.pw.sub[0];
+                    S.x += t.x; S.y += t.y; S.z += t.z;
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) voxel_store(v, S.x / (double)cnt, S.y / (double)cnt, S.z / (double)cnt, out_pts, out_xyz);
+        }
+        return;
+    }
+    // mode 2
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* const buf0 = L.run[wave][0];
+    double* const buf1 = L.run[wave][1];
+    constexpr int PER = 3 * VOX_RUN_CHUNK / 64;   // doubles per lane and chunk
+    for (unsigned int b = blockIdx.x * 4 + wave; b < nb; b += gridDim.x * 4) {
+        const unsigned int v = big_list[b];
+        const unsigned int s = heads[v], e = v + 1 < ng ? heads[v + 1] : (unsigned int)n;
+        const unsigned int cnt = e - s;
+        const double* const src = reinterpret_cast<const double*>(xyz + s);
+        const unsigned int total = 3u * cnt;   // doubles
+        double r[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const unsigned int i = lane + 64 * u; r[u] = i < total ? src[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) buf0[lane + 64 * u] = r[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double acc = 0.0;   // lane 0: x, lane 1: y, lane 2: z
+        const unsigned int n_chunks = (cnt + VOX_RUN_CHUNK - 1) / VOX_RUN_CHUNK;
+        for (unsigned int c = 0; c < n_chunks; ++c) {
+            const bool more = c + 1 < n_chunks;
+            if (more) {
+                const unsigned int base = 3u * VOX_RUN_CHUNK * (c + 1);
+#pragma unroll
+                for (int u = 0; u < PER; ++u) { const unsigned int i = base + lane + 64 * u; r[u] = i < total ? src[i] : 0.0; }
+            }
+            const double* const cur = (c & 1) ? buf1 : buf0;
+            const unsigned int m = cnt - c * VOX_RUN_CHUNK < (unsigned int)VOX_RUN_CHUNK ? cnt - c * VOX_RUN_CHUNK : (unsigned int)VOX_RUN_CHUNK;
+            if (lane < 3) {
+                unsigned int k = 0;
+                for (; k + 8 <= m; k += 8) {
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = cur[3 * (k + u) + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += t[u];
+                }
+                for (; k < m; ++k) acc += cur[3 * k + lane];
+            }
+            if (more) {
+                double* const nxt = (c & 1) ? buf0 : buf1;
+#pragma unroll
+                for (int u = 0; u < PER; ++u) nxt[lane + 64 * u] = r[u];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        acc /= (double)cnt;
+        const double ox = __shfl(acc, 0, 64), oy = __shfl(acc, 1, 64), oz = __shfl(acc, 2, 64);
+        if (lane == 0) voxel_store(v, ox, oy, oz, out_pts, out_xyz);
     }
 }
 
@@ -222,6 +385,8 @@ struct voxel_work {
     vox_xyz* xyz = nullptr;         // coordinates in voxel-major order
     unsigned int* heads = nullptr;  // group start positions
     unsigned int* n_groups = nullptr;
+    unsigned int* big_list = nullptr;   // voxels too populous for a lane group (voxel_emit_big_kernel), <= n / 65 + 1 entries
+    unsigned int* big_count = nullptr;
     int64_t n = 0;
 };
 
@@ -245,7 +410,8 @@ static int voxel_groups(pcr_ctx* ctx, const pcr_cloud* c, double leaf, int end_b
     };
     if ((rc = pcr_dev_alloc(ctx, sizeof(K) * n, (void**)&d_keys)) || (rc = pcr_dev_alloc(ctx, sizeof(K) * n, (void**)&d_keys2)) ||
         (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_vals)) || (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * n, (void**)&d_perm)) ||
-        (rc = pcr_dev_alloc(ctx, sizeof(vox_xyz) * n, (void**)&w->xyz)) || (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (n + 1), (void**)&w->heads))) {
+        (rc = pcr_dev_alloc(ctx, sizeof(vox_xyz) * n, (void**)&w->xyz)) || (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (n + 1), (void**)&w->heads)) ||
+        (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (n / 65 + 1), (void**)&w->big_list))) {
         release();
         return rc;
     }
@@ -255,7 +421,8 @@ static int voxel_groups(pcr_ctx* ctx, const pcr_cloud* c, double leaf, int end_b
     if (e == hipSuccess) rc = pcr_dev_alloc(ctx, temp_bytes, &d_temp);
     if (e == hipSuccess && rc == PCR_OK) e = pcr_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_perm, (size_t)n, (unsigned int)end_bit, ctx->stream);
     if (e == hipSuccess && rc == PCR_OK) {
-        hipLaunchKernelGGL(voxel_gather_kernel, dim3(grid_n), dim3(256), 0, ctx->stream, (const pcr_pt*)c->d, (const unsigned int*)d_perm, n, w->xyz);
+        w->big_count = ctx->d_counters + 49;
+        hipLaunchKernelGGL(voxel_gather_kernel, dim3(grid_n), dim3(256), 0, ctx->stream, (const pcr_pt*)c->d, (const unsigned int*)d_perm, n, w->xyz, w->big_count);
         // group heads = positions whose key differs from the previous one: one fused flag + scan + scatter (rocprim::select
         // over a counting iterator with a computed flag), instead of a flag kernel, a scan and a scatter
         w->n_groups = ctx->d_counters + 48;
@@ -317,8 +484,10 @@ static int voxel_prepare(pcr_ctx* ctx, const pcr_cloud* c, double leaf, double* 
 static void voxel_release(pcr_ctx* ctx, voxel_work* w) {
     if (w->xyz) pcr_dev_free(ctx, w->xyz, sizeof(vox_xyz) * w->n);
     if (w->heads) pcr_dev_free(ctx, w->heads, sizeof(unsigned int) * (w->n + 1));
+    if (w->big_list) pcr_dev_free(ctx, w->big_list, sizeof(unsigned int) * (w->n / 65 + 1));
     w->xyz = nullptr;
     w->heads = nullptr;
+    w->big_list = nullptr;
 }
 
 extern "C" {
@@ -358,7 +527,16 @@ static int voxel_filter_impl(pcr_ctx* ctx, const pcr_cloud* in, double leaf, int
         if (blocks > 16ll * ctx->cu_count) blocks = 16ll * ctx->cu_count;
         hipLaunchKernelGGL(voxel_emit_kernel, dim3((unsigned)blocks), dim3(block), 0, ctx->stream,
                            (const vox_xyz*)w.xyz, (const unsigned int*)w.heads, (const unsigned int*)w.n_groups,
-                           (long long)in->n, mode, (unsigned long long)seed, out_pts, out_xyz_dev);
+                           (long long)in->n, mode, (unsigned long long)seed, out_pts, out_xyz_dev, w.big_count, w.big_list);
+        if (mode != 1) {
+            // what the lane groups left on the list (usually nothing at fine leaves: the blocks read the count and leave)
+            long long big_max = in->n / (voxel_big_threshold(mode) + 1) + 1;
+            if (mode == 2) big_max = (big_max + 3) / 4;
+            if (big_max > 8ll * ctx->cu_count) big_max = 8ll * ctx->cu_count;
+            hipLaunchKernelGGL(voxel_emit_big_kernel, dim3((unsigned)big_max), dim3(256), 0, ctx->stream, (const vox_xyz*)w.xyz, (const unsigned int*)w.heads,
+                               (const unsigned int*)w.n_groups, (long long)in->n, mode, out_pts, out_xyz_dev, (const unsigned int*)w.big_count,
+                               (const unsigned int*)w.big_list);
+        }
         PCR_HIP(ctx, hipGetLastError());
     }
     unsigned int ng = 0;

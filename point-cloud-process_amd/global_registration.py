@@ -51,6 +51,100 @@ class RegistrationResult:
                 f"and correspondence_set size of {len(self.correspondence_set)}")
 
 
+class _Prep:
+    """Owner of a pcr_prep handle (preprocess_point_cloud's result, resident on the device)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._h = ctx, handle
+        self.n = int(L.lib().pcr_prep_size(handle))
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("preprocessed cloud freed")
+        return self._h
+
+    def download(self, points=False, normals=False, features=False):
+        out = [np.empty((self.n, 3)) if points else None, np.empty((self.n, 3)) if normals else None, np.empty((self.n, 33)) if features else None]
+        L.check(L.lib().pcr_prep_download(self.ctx.handle, self.handle, *[L.dptr(a) if a is not None else None for a in out]), self.ctx.handle)
+        return out
+
+    def cloud(self):
+        """Non-owning DeviceCloud view of the down-sampled cloud."""
+        c = DeviceCloud(self.ctx, C.c_void_p(L.lib().pcr_prep_cloud(self.handle)), self.n)
+        c.free = lambda: None   # the prep owns it
+        return c
+
+    def free(self):
+        if self._h:
+            L.lib().pcr_prep_free(self.ctx.handle, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PreparedCloud(PointCloud):
+    """pcd_down of preprocess_point_cloud (main.py:35-40): ``.points`` / ``.normals`` are fetched from the device on first use."""
+
+    def __init__(self, prep):
+        self._prep = prep
+        self._points = self._normals = None
+
+    @property
+    def points(self):
+        if self._points is None:
+            self._points = self._prep.download(points=True)[0]
+        return self._points
+
+    @points.setter
+    def points(self, v):   # (transform() and callers may replace them: the object then no longer stands for the device copy)
+        self._points = np.asarray(v, dtype=np.float64)
+        self._prep = None
+
+    @property
+    def normals(self):
+        if self._normals is None and self._prep is not None:
+            self._normals = self._prep.download(normals=True)[1]
+        return self._normals
+
+    @normals.setter
+    def normals(self, v):
+        self._normals = None if v is None else np.asarray(v, dtype=np.float64)
+
+    def __len__(self):
+        return self._prep.n if self._prep is not None else len(self._points)
+
+
+class PreparedFeature(Feature):
+    """pcd_fpfh of preprocess_point_cloud (main.py:44-46): ``.data`` (33, N) is fetched from the device on first use."""
+
+    def __init__(self, prep):
+        self._prep = prep
+        self._data = None
+
+    @property
+    def data(self):
+        if self._data is None:
+            self._data = np.ascontiguousarray(self._prep.download(features=True)[2].T)
+        return self._data
+
+    def dimension(self):
+        return 33
+
+    def num(self):
+        return self._prep.n
+
+
+def _prep_of(down, feature, ctx):
+    """The device-resident prep behind (pcd_down, pcd_fpfh) when both still stand for it (same device)."""
+    a, b = getattr(down, "_prep", None), getattr(feature, "_prep", None)
+    return a if (a is not None and a is b and a._h and a.ctx.device == ctx.device) else None
+
+
 def _cloud(points, ctx):
     if isinstance(points, DeviceCloud):
         return points, None
@@ -151,13 +245,29 @@ def _ransac(src_cloud, tgt_cloud, corr, max_distance, edge_similarity, check_dis
 
 def registration_ransac_based_on_feature_matching(source, target, source_feature, target_feature, mutual_filter=True,
                                                   max_correspondence_distance=3.0, ransac_n=3, edge_length_similarity=0.9,
-                                                  check_distance=True, max_iteration=100000, confidence=0.999, seed=0, ctx=None):
+                                                  check_distance=True, max_iteration=100000, confidence=0.999, seed=0, ctx=None, evaluate=True):
     """o3d.pipelines.registration.registration_ransac_based_on_feature_matching as called at main.py:73-83
     (point-to-point estimation without scaling, ransac_n = 3, edge-length + distance checkers,
     RANSACConvergenceCriteria(max_iteration, confidence)).  The random stream is counter-based and seeded."""
     if ransac_n != 3:
         raise ValueError("only ransac_n = 3 (main.py:76) is implemented")
     ctx = ctx or default_context()
+    ps, pt = _prep_of(source, source_feature, ctx), _prep_of(target, target_feature, ctx)
+    if ps is not None and pt is not None:
+        # both sides are still on the device: matching, mutual filter and the RANSAC loop in one native call
+        p = L.RansacParams()
+        L.lib().pcr_ransac_default_params(C.byref(p))
+        p.max_iteration, p.confidence, p.max_distance = int(max_iteration), float(confidence), float(max_correspondence_distance)
+        p.edge_similarity, p.check_distance, p.seed = float(edge_length_similarity), 1 if check_distance else 0, int(seed) & 0xFFFFFFFFFFFFFFFF
+        res = L.RansacResult()
+        st = L.lib().pcr_global_registration(ctx.handle, ps.handle, pt.handle, C.byref(p), 1 if mutual_filter else 0, C.byref(res))
+        L.check(st, ctx.handle)
+        T = np.array(res.T, dtype=np.float64).reshape(4, 4)
+        info = {"iterations": res.iterations, "n_valid": res.n_valid, "best_iteration": res.best_iteration, "corr_fitness": res.corr_fitness,
+                "corr_rmse": res.corr_rmse, "n_correspondences": res.reserved_i, "status": st}
+        if not evaluate:
+            return RegistrationResult(T, res.corr_fitness, res.corr_rmse, None, info)
+        return _evaluate(ps.cloud(), pt.cloud(), T, max_correspondence_distance, info, ctx)
     fa = np.ascontiguousarray(np.asarray(getattr(source_feature, "data", source_feature), dtype=np.float64).T)
     fb = np.ascontiguousarray(np.asarray(getattr(target_feature, "data", target_feature), dtype=np.float64).T)
     ij, _ = _match(fa, fb, ctx)
@@ -173,7 +283,17 @@ def registration_ransac_based_on_feature_matching(source, target, source_feature
     T = np.array(res.T, dtype=np.float64).reshape(4, 4)
     info = {"iterations": res.iterations, "n_valid": res.n_valid, "best_iteration": res.best_iteration, "corr_fitness": res.corr_fitness,
             "corr_rmse": res.corr_rmse, "n_correspondences": len(corr), "status": st}
-    # final evaluation over the whole source cloud (GetRegistrationResultAndCorrespondences)
+    try:
+        return _evaluate(src, tgt, T, max_correspondence_distance, info, ctx) if evaluate else RegistrationResult(T, res.corr_fitness, res.corr_rmse, None, info)
+    finally:
+        for own in (own_s, own_t):
+            if own is not None:
+                own.free()
+
+
+def _evaluate(src, tgt, T, max_correspondence_distance, info, ctx):
+    """Open3D's final evaluation over the whole source cloud (GetRegistrationResultAndCorrespondences): fitness, inlier_rmse and
+    the correspondence set of the RegistrationResult (main.py:211 itself only reads .transformation)."""
     index = TargetIndex(tgt, ctx=ctx)
     idx, d2 = index.nn1(src, T=T)
     index.free()
@@ -181,28 +301,23 @@ def registration_ransac_based_on_feature_matching(source, target, source_feature
     fitness = len(inl) / max(src.n, 1)
     rmse = float(np.sqrt(d2[inl].sum() / len(inl))) if len(inl) else 0.0
     cset = np.stack([inl, idx[inl]], axis=1).astype(np.int32)
-    for own in (own_s, own_t):
-        if own is not None:
-            own.free()
     return RegistrationResult(T, fitness, rmse, cset, info)
 
 
 def preprocess_point_cloud(pcd, voxel_size, ctx=None):
     """main.py:33-47 -> (pcd_down with .points/.normals, pcd_fpfh): down-sample at voxel_size, normals with radius
-    2*voxel_size / 30 neighbours, FPFH with radius 5*voxel_size / 100 neighbours."""
+    2*voxel_size / 30 neighbours, FPFH with radius 5*voxel_size / 100 neighbours -- one native call (pcr_preprocess); both
+    results stay on the device and come over only when their arrays are looked at."""
     ctx = ctx or default_context()
     full, own = _cloud(pcd, ctx)
     h = C.c_void_p()
-    # mode 2 = Open3D's voxel_down_sample; the down-sampled cloud stays on the device for the normals and the descriptor
-    L.check(L.lib().pcr_voxel_filter_cloud(ctx.handle, full.handle, float(voxel_size), 2, C.c_uint64(0), C.byref(h)), ctx.handle)
-    cloud = DeviceCloud(ctx, h, L.lib().pcr_cloud_size(h))
-    if own is not None:
-        own.free()
-    down = PointCloud(cloud.download())
-    down.normals = estimate_normals_hybrid(cloud, voxel_size * 2, 30, ctx=ctx)
-    fpfh = compute_fpfh_feature(cloud, down.normals, voxel_size * 5, 100, ctx=ctx)
-    cloud.free()
-    return down, fpfh
+    try:
+        L.check(L.lib().pcr_preprocess(ctx.handle, full.handle, float(voxel_size), float(voxel_size) * 2, 30, float(voxel_size) * 5, 100, C.byref(h)), ctx.handle)
+    finally:
+        if own is not None:
+            own.free()
+    prep = _Prep(ctx, h)
+    return PreparedCloud(prep), PreparedFeature(prep)
 
 
 def prepare_dataset(path_src, path_trg, voxel_size, ctx=None):
@@ -215,10 +330,11 @@ def prepare_dataset(path_src, path_trg, voxel_size, ctx=None):
     return source, target, source_down, target_down, source_fpfh, target_fpfh
 
 
-def execute_global_registration(source_down, target_down, source_fpfh, target_fpfh, voxel_size, seed=0, ctx=None):
-    """main.py:68-84: distance threshold 1.5 * voxel_size, 100000 iterations / 0.999 confidence."""
+def execute_global_registration(source_down, target_down, source_fpfh, target_fpfh, voxel_size, seed=0, ctx=None, evaluate=True):
+    """main.py:68-84: distance threshold 1.5 * voxel_size, 100000 iterations / 0.999 confidence.  ``evaluate=False`` skips the
+    whole-cloud fitness / inlier_rmse of the returned RegistrationResult (main.py:211 reads .transformation only)."""
     return registration_ransac_based_on_feature_matching(
-        source_down, target_down, source_fpfh, target_fpfh, True, voxel_size * 1.5, 3, 0.9, True, 100000, 0.999, seed=seed, ctx=ctx)
+        source_down, target_down, source_fpfh, target_fpfh, True, voxel_size * 1.5, 3, 0.9, True, 100000, 0.999, seed=seed, ctx=ctx, evaluate=evaluate)
 
 
 def ransac_init(src_cloud, tgt_cloud, voxel_size=2.0, seed=0, ctx=None, detector="voxel", iss_radius=None, iss_count=400,

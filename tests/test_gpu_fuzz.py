@@ -105,6 +105,62 @@ def test_voxel_filter_fuzz_bit_exact(pcp, oracle, case):
         assert out.shape == ref.shape and np.array_equal(out, ref)
 
 
+def _populous(rng, counts, f32=False, shift=0.0):
+    """One unit cube per entry of `counts` along x (cube i holds counts[i] points), then a final singleton voxel (the group the
+    reference never emits); shuffled, so that the input order inside a voxel is not the storage order.  `shift` = 0.5 aligns the
+    cubes with Open3D's voxels (origin = min - voxel / 2)."""
+    parts = [rng.uniform(0.0, 1.0, (c, 3)) * 0.998 + 0.001 + np.array([float(i), 0.0, 0.0]) + shift for i, c in enumerate(counts)]
+    parts.append(np.array([[len(counts) + 0.5, 0.5, 0.5]]) + shift)
+    parts.append(np.array([[0.0, 0.0, 0.0], [len(counts) + 1.0 + shift, 1.0 + shift, 1.0 + shift]]))     # pins min / max: voxel i = cube i at leaf 1
+    pts = np.concatenate(parts)
+    rng.shuffle(pts)
+    return pts.astype(np.float32).astype(np.float64) if f32 else pts
+
+
+def test_voxel_filter_populous_voxels_bit_exact(pcp, oracle):
+    """Voxels far above a lane group's reach (voxel_filter.py:36-51 walks them point by point; np.mean = NumPy's pairwise
+    recursion): every size class of the split -- the 1024-point hand-over to a block, the depths at which all nodes split,
+    subtrees whose sizes differ by the recursion's rounding to multiples of 8 -- must reproduce np.mean bit for bit."""
+    rng = np.random.default_rng(4242)
+    counts = [1023, 1024, 1025, 1031, 1032, 1033, 1039, 1040, 2047, 2048, 2049, 2063, 2064, 2065, 3000, 4095, 4096, 4097, 4104, 4111, 4112,
+              5000, 8191, 8192, 8193, 8200, 8264, 16390, 33000, 70001]
+    pts = _populous(rng, counts)
+    out = pcp.voxel_filter(pts, 1.0, "centroid")
+    ref = oracle.voxel_filter(pts, 1.0, "centroid")[0]
+    assert out.shape == ref.shape and len(ref) >= len(counts)
+    assert np.array_equal(out, ref)
+    # every listed cube is one voxel of that many points (+ the pinned corner in cube 0)
+    h, _ = oracle.voxel_keys(pts, 1.0)
+    sizes = np.unique(h, return_counts=True)[1]
+    assert sorted(sizes.tolist())[-3:] == [16390, 33000, 70001]
+
+
+def test_voxel_filter_2m_leaf_on_1m_points(pcp, oracle, syn):
+    """The coarse levels of BASELINE configs[4]'s coarse-to-fine ICP: 2 m and 0.5 m leaves on a 1 M-point scan (voxels of tens of
+    thousands of points next to the sensor)."""
+    pts = syn.kitti_like_scan(1_000_000, seed=11).astype(np.float64)
+    for leaf in (2.0, 0.5):
+        out = pcp.voxel_filter(pts, leaf, "centroid")
+        ref = oracle.voxel_filter(pts, leaf, "centroid")[0]
+        assert out.shape == ref.shape and np.array_equal(out, ref), leaf
+
+
+def test_voxel_down_sample_populous_voxels_running_sum(pcp):
+    """Open3D's voxel_down_sample (Registration/main.py:35) adds a voxel's points in input order: binary64 inputs make every
+    addition round, so any other order of additions shows in the last bits.  PARITY UNPINNED (Open3D absent): checked against
+    oracle/oracle_global.py's restatement."""
+    import importlib
+    og = importlib.import_module("oracle.oracle_global")
+    rng = np.random.default_rng(4343)
+    counts = [1, 2, 7, 8, 9, 63, 64, 65, 66, 255, 256, 257, 258, 511, 512, 513, 1000, 10007, 40000]
+    pts = _populous(rng, counts, shift=0.5) * 2.0 + 50.0       # cubes of 2 m = voxels at voxel_size 2
+    pts = pts[:, [1, 0, 2]].copy()                    # cubes along y: the key order is not the x order
+    out = pcp.voxel_down_sample(pts, 2.0)
+    ref = og.voxel_down_sample(pts, 2.0)
+    assert out.shape == ref.shape and np.array_equal(out, ref)
+    assert len(ref) == len(counts) + 3              # one voxel per cube + the singleton + the two corners
+
+
 def test_voxel_filter_huge_grid_keys_beyond_2_53(pcp, oracle):
     """A tiny leaf on a large extent: h = hx + hy*Dx + hz*Dx*Dy leaves the exactly representable integers (> 2^53, here even
     > 2^64).  The reference sorts the float64 h itself (voxel_filter.py:36); the device then sorts the BIT PATTERN of h

@@ -211,6 +211,58 @@ def test_icp_batch_fused_stages_bitwise_equal_per_pair_path(pcp, syn, monkeypatc
     monkeypatch.delenv("PCR_BATCH_SUB")
 
 
+def test_icp_batch_scans_shared_between_pairs(pcp, syn, monkeypatch):
+    """Registration/reg_result.txt registers 342 pairs over 504 scans: a scan that several pairs of a call use is packed and brought
+    over ONCE (by the first sub-batch that uses it; later sub-batches read its device copy behind an event, a later slot of the same
+    sub-batch reads the same staging rows).  Chains of pairs over eight scans -- also one whose owner pair is not taken by the fused
+    stages (its other cloud is empty) and a scan with a NaN that two pairs share -- through several sub-batch sizes and worker
+    counts: every result bit for bit what the per-pair path gives."""
+    batch = __import__("importlib").import_module("point-cloud-process_amd.batch")
+    poses = [syn.rigid_transform((0, 0, 1), 0.015 * i, (0.25 * i, 0.05 * i, 0)) for i in range(8)]
+    scans = [syn.kitti_like_scan(int(n), seed=900 + i, sensor_pose=P) for i, (n, P) in enumerate(zip([9000, 700, 15000, 4000, 12000, 2500, 20000, 6000], poses))]
+    nan_scan = scans[5].copy()
+    nan_scan[11, 2] = np.nan
+    empty = np.zeros((0, 3), np.float32)
+    order = [(1, 0), (2, 1), (2, 0), (3, 2), (4, 3), (0, 4), (6, 4), (7, 6), (6, 2), (1, 7), (5, 6), (3, 0)]
+    pairs = [(scans[a], scans[b], None if i % 4 else syn.rigid_transform((0, 0, 1), 0.01, (0.05, 0, 0))) for i, (a, b) in enumerate(order)]
+    pairs.insert(2, (nan_scan, scans[3], None))
+    pairs.append((scans[2], nan_scan, None))
+    kw = dict(mode="total", max_iter=12, r_thres=1e-4, t_thres=1e-4)
+    keys = ("iters", "status", "n_assoc", "cost", "mean_d2")
+    monkeypatch.setenv("PCR_BATCH_PER_PAIR", "1")
+    ref = batch.native_register_share(pairs, device=0, streams=1, **kw)
+    monkeypatch.setenv("PCR_BATCH_PER_PAIR", "0")
+    assert batch.native_calls[-1][1:3] == (len(pairs), 9)          # 14 pairs over 9 scans (the eight + the NaN copy)
+    for sub, streams in ((1, 3), (2, 2), (3, 4), (5, 1), (64, 2)):
+        monkeypatch.setenv("PCR_BATCH_SUB", str(sub))
+        got = batch.native_register_share(pairs, device=0, streams=streams, **kw)
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert all(a[k] == b[k] for k in keys), (sub, i, {k: (a[k], b[k]) for k in keys})
+            assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["T_total"], b["T_total"]), (sub, i)
+    # the owner of a shared scan is a pair the fused stages do not take (empty source): the scan still reaches the later sub-batch
+    monkeypatch.setenv("PCR_BATCH_SUB", "1")
+    import ctypes as C
+    L = pcp._lib
+    use = [(empty, scans[0]), (scans[1], scans[0]), (scans[2], scans[0])]
+    parr = np.zeros(3, dtype=batch._PAIR_DT)
+    for i, (s_, t_) in enumerate(use):
+        parr[i] = (s_.ctypes.data if len(s_) else 0, s_.shape[0], 3, t_.ctypes.data, t_.shape[0], 3, 0)
+    p = L.IcpParams()
+    L.lib().pcr_icp_default_params(C.byref(p))
+    res = np.zeros(3, dtype=batch._RESULT_DT)
+    status = np.zeros(3, dtype=np.int32)
+    ctxs = batch._pooled_contexts(0, 2)
+    handles = (C.c_void_p * 2)(*[c.handle for c in ctxs])
+    rc = L.lib().pcr_icp_batch(handles, 2, parr.ctypes.data_as(C.POINTER(L.Pair)), 3, C.byref(p), res.ctypes.data_as(C.POINTER(L.IcpResult)), L.iptr(status))
+    assert rc == L.PCR_E_EMPTY and status[0] == L.PCR_E_EMPTY and status[1] == 0 and status[2] == 0
+    monkeypatch.setenv("PCR_BATCH_PER_PAIR", "1")
+    one = batch.native_register_share([(scans[1], scans[0], None), (scans[2], scans[0], None)], device=0, streams=1)
+    monkeypatch.setenv("PCR_BATCH_PER_PAIR", "0")
+    monkeypatch.delenv("PCR_BATCH_SUB")
+    for i in (0, 1):
+        assert np.array_equal(res["T"][i + 1].reshape(4, 4), one[i]["T"]) and res["iters"][i + 1] == one[i]["iters"]
+
+
 def test_icp_batch_bad_pairs_do_not_poison_the_batch(pcp, syn, monkeypatch):
     """An empty cloud inside a batch: that pair's status is a hard error (and the call's return value), every other pair still
     gets its result (per-pair failure must not poison a batch).  A NaN coordinate is not an error of the path (such a
