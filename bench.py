@@ -402,6 +402,75 @@ def config3_leg(pkg, ctx, src, tgt):
     return res
 
 
+def global_init_leg(pkg, ctx, src, tgt, dev_id, streams):
+    """The stage in front of ICP in the reference's pair loop (Registration/main.py:196-203: prepare_dataset ->
+    execute_global_registration; Open3D there, "parity unpinned" here): ms per step on the bench's 120k pair through the C ABI
+    (device-resident where the ABI allows it), the whole stage from host arrays, and BASELINE configs[3]'s 256 pairs with the
+    initialisation inside the rank's one native call (pcr_register_pairs)."""
+    batch = importlib.import_module("point-cloud-process_amd.batch")
+    glob = importlib.import_module("point-cloud-process_amd.global_registration")
+
+    def best(fn, reps=7):
+        fn()
+        t_best = None
+        for _ in range(reps):
+            ctx.sync()
+            t0 = time.perf_counter()
+            r = fn()
+            ctx.sync()
+            el = 1e3 * (time.perf_counter() - t0)
+            t_best = el if t_best is None else min(t_best, el)
+        return t_best, r
+
+    out = {"voxel_size_m": 2.0, "points": [int(len(src)), int(len(tgt))]}
+    ds, dt = pkg.DeviceCloud.upload(src, ctx), pkg.DeviceCloud.upload(tgt, ctx)
+    out["upload_ms"], _ = best(lambda: pkg.DeviceCloud.upload(src, ctx).free())
+    down_ms, down = best(lambda: glob.voxel_down_sample_device(ds, 2.0, ctx=ctx))
+    out["down_sample_ms"] = down_ms
+    out["rows_after_down_sample"] = [int(down.n), int(glob.voxel_down_sample_device(dt, 2.0, ctx=ctx).n)]
+    out["normals_ms"], nrm = best(lambda: pkg.estimate_normals_hybrid(down, 4.0, 30, ctx=ctx))
+    out["fpfh_ms"], _ = best(lambda: pkg.compute_fpfh_feature(down, nrm, 10.0, 100, ctx=ctx))
+    out["preprocess_ms"], ps = best(lambda: pkg.preprocess_point_cloud(ds, 2.0, ctx=ctx))
+    pt = pkg.preprocess_point_cloud(dt, 2.0, ctx=ctx)
+    fs, ft = ps[1].data, pt[1].data
+    out["match_both_ways_ms"], _ = best(lambda: pkg.find_matchings(fs, ft, ctx=ctx))
+    out["registration_ms"], res = best(lambda: pkg.execute_global_registration(ps[0], pt[0], ps[1], pt[1], 2.0, seed=1, ctx=ctx, evaluate=False))
+    out["ransac"] = {k: res.info[k] for k in ("iterations", "n_valid", "best_iteration", "n_correspondences", "corr_fitness")}
+
+    def whole():
+        a = pkg.preprocess_point_cloud(pkg.DeviceCloud.upload(src, ctx), 2.0, ctx=ctx)
+        b = pkg.preprocess_point_cloud(pkg.DeviceCloud.upload(tgt, ctx), 2.0, ctx=ctx)
+        return pkg.execute_global_registration(a[0], b[0], a[1], b[1], 2.0, seed=1, ctx=ctx, evaluate=False)
+
+    out["whole_stage_ms_per_pair_from_host_arrays"], _ = best(whole)
+    out["note"] = ("wall ms, best of 7, one context; down_sample / normals / fpfh / match are the single-step entry points (small host copies "
+                   "in and out included), preprocess = pcr_preprocess (down-sample + normals + FPFH, nothing leaves the device), registration = "
+                   "pcr_global_registration (matching both ways + mutual filter + RANSAC loop on the device, one synchronisation)")
+    ds.free()
+    dt.free()
+    # configs[3] with the initialisation: every pair 20 degrees / 2.2 m apart, so that the stage has something to find
+    P = BATCH_PAIRS
+    pairs = []
+    for i in range(P):
+        s_, t_, _ = pkg.synthetic.perturbed_pair(BATCH_POINTS, seed=3000 + i, angle_deg=20.0 + (i % 7), t=(2.0 + 0.1 * (i % 5), -1.0, 0.05))
+        pairs.append((s_, t_, None))
+    kw = dict(mode="total", max_iter=30, r_thres=1e-3, t_thres=1e-3)
+    rows = {}
+    for tag, gi in (("icp_only", None), ("with_global_init", True)):
+        batch.register_batch(pairs, device=dev_id, streams=streams, global_init=gi, **kw)
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = batch.register_batch(pairs, device=dev_id, streams=streams, global_init=gi, **kw)
+            runs.append(time.perf_counter() - t0)
+        rows[tag] = {"seconds": min(runs), "pairs_per_s": P / min(runs), "runs_s": runs, "mean_iters": float(np.mean([x["iters"] for x in r]))}
+    rows["global_init_ms_per_pair"] = 1e3 * (rows["with_global_init"]["seconds"] - rows["icp_only"]["seconds"]) / P
+    rows["pairs"], rows["points_per_cloud"], rows["streams_per_gpu"] = P, BATCH_POINTS, streams
+    rows["entry_point"] = "register_batch(pairs, global_init=True) -> pcr_register_pairs: every scan preprocessed once per call, one pcr_global_registration per pair, T0 into the fused ICP batch"
+    out["batch256"] = rows
+    return out
+
+
 def config5_leg(pkg, ctx):
     """BASELINE configs[4]: 1 M-point synthetic scan (8 KITTI-shaped frames of one world): ISS keypoints with radius-NN
     covariance (Keypoint_detection_ISS/ISS.py:35-73) and a coarse-to-fine ICP that ends on 1 M x 1 M points."""
@@ -652,6 +721,7 @@ def main():
         if world == 1 and a.nn == "grid" and not a.no_configs and a.points == N_POINTS:
             line["config3"] = config3_leg(pkg, ctx, src, tgt)
             line["config5"] = config5_leg(pkg, ctx)
+            line["global_init"] = global_init_leg(pkg, ctx, src, tgt, dev_id, a.batch_streams)
         if world == 1 and a.nn == "grid" and a.in_flight > 1:
             line["concurrent_pairs"] = concurrent_leg(pkg, dev_id, src, tgt, a.in_flight, min(a.steps, 100))
         if world == 1 and not a.no_cpu:

@@ -135,7 +135,7 @@ typedef struct pcr_icp_result {
     double mean_d2;        /* mean squared NN distance of the last association pass     */
     double r_diff[PCR_ICP_MAX_LOG]; /* log["R_diff"], icp_template.py:189 */
     double t_diff[PCR_ICP_MAX_LOG]; /* log["t_diff"], icp_template.py:190 */
-    double device_ms;      /* HIP-event time of the whole loop on the ctx stream        */
+    double device_ms;      /* duration of the whole loop on the device: the kernels' own 100-MHz clock, first kernel .. end of the last pass (device-resident loop), HIP events otherwise */
     double nn_kernel_ms;   /* sum of HIP-event times of the pass kernels; 0 unless pcr_profile_enable(ctx, 1) (host loop: always) */
     int32_t nn_launches;   /* launches of the correspondence kernel                     */
     int32_t reserved;
@@ -340,9 +340,21 @@ PCR_API int pcr_timer_stop_ms(pcr_ctx* ctx, double* ms_out);
 PCR_API int pcr_debug_read(pcr_ctx* ctx, uint64_t* out, int64_t n_words);
 PCR_API int pcr_profile_enable(pcr_ctx* ctx, int on);
 /* diagnostics of the LAST correspondence search on this context (Registration/main.py:116-121 is the step they describe):
- * out[0] = queries the brute-force MFMA sweep could not prove and re-did with the exact direct-form sweep,
- * out[1..3] reserved (0).  Exactness never depends on these numbers; tests use them to see the fallback fire.   */
+ * out[0] = queries the brute-force MFMA sweep could not prove and re-did with the exact direct-form sweep;
+ * out[1] = device arenas (256-MiB hipMalloc blocks the context's buffers are carved from) allocated since the context was
+ * created, out[2] = microseconds of host time those allocations took, out[3] = arenas held now: a call that had to grow an
+ * arena pays milliseconds on the host with its stream idle, and a caller timing calls can name that.
+ * Exactness never depends on these numbers; tests use out[0] to see the fallback fire.   */
 PCR_API int pcr_search_stats(pcr_ctx* ctx, int64_t out[4]);
+
+/* Per-pass log of the LAST pcr_icp call on this context that ran the device-resident loop (grid index, gated): for every association
+ * pass (Registration/main.py:107-154 is one) the duration of its tile launch -- of the whole pass when it ran as one launch --, of
+ * its drain launch (0 for a one-launch pass) and the queries the tiles handed to the work queue (two-launch passes), from the
+ * kernels' own 100-MHz timestamps.  *n_out = passes logged (<= PCR_ICP_MAX_LOG); at most max_n entries are written.
+ * host_us (may be NULL): the call on the host, microseconds -- [0] set-up before the first launch, [1] enqueueing the first chunk
+ * of passes, [2] waiting for the device (all synchronisations), [3] the whole loop, [4] by HIP events: from the start of the call to
+ * behind the last kernel of the last chunk (in front of the read-back of the loop state), [5] the last wait alone.                 */
+PCR_API int pcr_icp_pass_log(pcr_ctx* ctx, int max_n, double* tile_us, double* drain_us, int64_t* items, int* n_out, double host_us[6]);
 
 /* Scheduling hint: shared != 0 tells the library that other contexts keep the same device busy while this one runs ICP
  * loops (a batch worker: Registration/main.py:190-216 spread over several streams).  The ICP pass then runs as two launches

@@ -185,6 +185,7 @@ SIGNATURES = {
     "pcr_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "pcr_search_stats": (C.c_int, [_vp, _lp]),
     "pcr_ctx_set_shared": (C.c_int, [_vp, C.c_int]),
+    "pcr_icp_pass_log": (C.c_int, [_vp, C.c_int, _dp, _dp, _lp, C.POINTER(C.c_int), _dp]),
     "pcr_timer_start": (C.c_int, [_vp]),
     "pcr_timer_stop_ms": (C.c_int, [_vp, _dp]),
 }

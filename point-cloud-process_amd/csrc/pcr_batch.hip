@@ -404,7 +404,7 @@ struct batch_timing {
 // pinned host memory of a context, grown on demand (hipHostMalloc pins pages under a process-wide lock: kept across batches)
 int ensure_pinned(pcr_ctx* ctx, size_t bytes) {
     if (ctx->h_stage_bytes >= bytes && ctx->h_stage) return PCR_OK;
-    hipStreamSynchronize(ctx->stream);
+    pcr_sync(ctx->stream);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     ctx->h_stage = nullptr;
     ctx->h_stage_bytes = 0;
@@ -830,7 +830,7 @@ int batch_job::end() {
     hipStream_t st = ctx->stream;
     int rc;
     for (;;) {
-        PCR_HIP(ctx, hipStreamSynchronize(st));
+        PCR_HIP(ctx, pcr_sync(st));
         if (params->max_iter <= 0 || *h_run == 0 || enq >= params->max_iter) break;
         if (!ctx->profile) chunk *= 2;
         if ((rc = enqueue_chunk())) return rc;
@@ -847,7 +847,7 @@ int batch_job::end() {
                            (unsigned long long)(sizeof(batch_plan) / 8), (unsigned long long)(sizeof(batch_plan) / 8));
     }
     PCR_HIP(ctx, hipGetLastError());
-    PCR_HIP(ctx, hipStreamSynchronize(st));
+    PCR_HIP(ctx, pcr_sync(st));
     if (h_plan->overflow) { ctx->last_error = "batch: table pool bound exceeded"; return PCR_E_HIP; }
     float icp_ms = 0;
     hipEventElapsedTime(&icp_ms, ctx->ev2, ctx->ev1);
@@ -1024,7 +1024,7 @@ int batch_run(pcr_ctx* const* ctxs, int n_ctx, batch_call& call, const pcr_icp_p
                     if (rc == PCR_OK) rc = J.end();
                 }
                 if (rc) {   // the whole sub-batch failed on the way (out of memory, HIP error): its pairs take the per-pair path
-                    hipStreamSynchronize(J.ctx->stream);
+                    pcr_sync(J.ctx->stream);
                     J.release();
                     for (int64_t i = S.lo; i < S.hi; ++i) status[i] = PCR_E_UNSUPPORTED;
                 }

@@ -576,7 +576,5 @@ int pcr_brute_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_pt* q, int64_t nq
 
 // diagnostics (tests, bench): queries the last brute-force search sent to the exact fallback
 int pcr_brute_last_fallback(pcr_ctx* ctx, unsigned int* out) {
-    PCR_HIP(ctx, hipMemcpyAsync(out, ctx->d_counters + BR_FLAG_SEEN_WORD, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PCR_OK;
+    return pcr_d2h_small(ctx, out, ctx->d_counters + BR_FLAG_SEEN_WORD, sizeof(unsigned int));
 }

@@ -62,7 +62,9 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
         delete c;
         return PCR_E_NOMEM;
     }
-    if (hipHostMalloc(&c->h_state, 8192, hipHostMallocDefault) != hipSuccess) { delete c; return PCR_E_NOMEM; }
+    // (device-mapped: small results are WRITTEN there by kernels, see pcr_d2h_small)
+    if (hipHostMalloc(&c->h_state, 8192, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete c; return PCR_E_NOMEM; }
+    if (hipHostMalloc(&c->h_small, PCR_SMALL_D2H_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete c; return PCR_E_NOMEM; }
     if (hipMalloc((void**)&c->d_counters, PCR_COUNTER_BYTES) != hipSuccess) { delete c; return PCR_E_NOMEM; }
     hipMemsetAsync(c->d_counters, 0, PCR_COUNTER_BYTES, c->stream);
     if (hipMalloc((void**)&c->d_cell_counts, 4 * (PCR_MAX_LEVELS * 64 + 64)) != hipSuccess) { delete c; return PCR_E_NOMEM; }
@@ -87,7 +89,7 @@ int pcr_ctx_create(int device, pcr_ctx** out) {
 int pcr_ctx_destroy(pcr_ctx* c) {
     if (!c) return PCR_OK;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    pcr_sync(c->stream);
     for (void* a : c->arenas) hipFree(a);
     if (c->d_partials) hipFree(c->d_partials);
     if (c->d_counters) hipFree(c->d_counters);
@@ -95,6 +97,7 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_slabs) hipHostFree(c->h_slabs);
     if (c->h_state) hipHostFree(c->h_state);
+    if (c->h_small) hipHostFree(c->h_small);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_down) hipHostFree(c->h_down);
     hipEventDestroy(c->ev0);
@@ -112,7 +115,7 @@ int pcr_ctx_destroy(pcr_ctx* c) {
 
 int pcr_ctx_sync(pcr_ctx* c) {
     if (!c) return PCR_E_INVALID;
-    PCR_HIP(c, hipStreamSynchronize(c->stream));
+    PCR_HIP(c, pcr_sync(c->stream));
     return PCR_OK;
 }
 
@@ -126,7 +129,7 @@ int pcr_ctx_device_info(pcr_ctx* c, char* name256, int* cu, int64_t* hbm) {
 
 int pcr_debug_read(pcr_ctx* c, uint64_t* out, int64_t n) {
     if (!c || !out || !c->d_debug || n > (1 << 20)) return PCR_E_INVALID;
-    PCR_HIP(c, hipStreamSynchronize(c->stream));
+    PCR_HIP(c, pcr_sync(c->stream));
     PCR_HIP(c, hipMemcpy(out, c->d_debug, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
     return PCR_OK;
 }
@@ -150,6 +153,72 @@ int pcr_profile_read(pcr_ctx* c, double ms_out[4], int* passes_out) {
 
 }  // extern "C"
 
+// Small device-to-host results WITHOUT the copy engine.  A hipMemcpyAsync of a few bytes or kilobytes behind the last kernel of a
+// call goes through the runtime's DMA path, and on this pool that path stalls at random: 1 M-point registrations whose kernels
+// had finished after their usual 13.5 ms (a HIP event behind the last kernel said so) returned after 30-57 ms, every 10th-30th
+// call, because the 4.5-KB read-back of the loop state behind them took 16-44 ms (the batch path had met the
+// same with its uploads in round 3).  So: a one-block kernel copies the bytes into a pinned, device-mapped block of the context,
+// the host waits for the stream (polling) and copies them out.
+__global__ void __launch_bounds__(256) d2h_small_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, unsigned int n) {
+    if (((((size_t)src) | ((size_t)dst) | n) & 3u) == 0u) {
+        const unsigned int* s4 = reinterpret_cast<const unsigned int*>(src);
+        unsigned int* d4 = reinterpret_cast<unsigned int*>(dst);
+        for (unsigned int i = threadIdx.x; i < n / 4; i += blockDim.x) d4[i] = s4[i];
+    } else
+        for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+// a sequence number into a mapped host word, behind everything the stream has done so far (system-scope release first): the host
+// can wait for it by reading memory, without asking the runtime
+__global__ void flag_kernel(unsigned long long* __restrict__ dst, unsigned long long seq) {
+    __threadfence_system();
+    __hip_atomic_store(dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Waits until everything enqueued on the context's stream so far has run: a flag kernel + polling of its mapped word (bounded), then
+// the runtime's own wait, which by then returns at once unless the flag never came.  *flag_us (may be null) = microseconds until the
+// flag was seen (-1: not within the bound).
+int pcr_wait_flag(pcr_ctx* ctx, double* flag_us) {
+    unsigned long long* const h_flag = (unsigned long long*)((char*)ctx->h_pinned + 1024);
+    unsigned long long* d_flag = nullptr;
+    PCR_HIP(ctx, hipHostGetDevicePointer((void**)&d_flag, h_flag, 0));
+    const unsigned long long seq = ++ctx->flag_seq;
+    hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(1), 0, ctx->stream, d_flag, seq);
+    PCR_HIP(ctx, hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (unsigned int spins = 0;; ++spins) {
+        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+        if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        __builtin_ia32_pause();
+    }
+    if (flag_us) *flag_us = seen ? std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() / 1e3 : -1.0;
+    if (!seen) PCR_HIP(ctx, pcr_sync(ctx->stream));
+    return PCR_OK;
+}
+
+int pcr_d2h_small_enqueue(pcr_ctx* ctx, void* mapped_host_dst, const void* dev_src, size_t bytes) {
+    void* dp = nullptr;
+    PCR_HIP(ctx, hipHostGetDevicePointer(&dp, mapped_host_dst, 0));
+    hipLaunchKernelGGL(d2h_small_kernel, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char*)dev_src, (unsigned char*)dp, (unsigned int)bytes);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_d2h_small(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    if (bytes == 0) return PCR_OK;
+    if (bytes > PCR_SMALL_D2H_BYTES || !ctx->h_small) {
+        PCR_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, pcr_sync(ctx->stream));
+        return PCR_OK;
+    }
+    const int rc = pcr_d2h_small_enqueue(ctx, ctx->h_small, dev_src, bytes);
+    if (rc) return rc;
+    PCR_HIP(ctx, pcr_sync(ctx->stream));
+    memcpy(host_dst, ctx->h_small, bytes);
+    return PCR_OK;
+}
+
 // Large device-to-host results (radius neighbour lists: 190 MB) through a pinned double buffer: the DMA of chunk i + 1 runs while
 // the host copies chunk i into the caller's (pageable) array.  Small copies and contexts that cannot get the buffer take the
 // plain path.  The stream is synchronised on return.
@@ -157,7 +226,7 @@ int pcr_d2h_staged(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t byt
     constexpr size_t HALF = 16u << 20;
     if (bytes < (48u << 20)) {   // (measured: 24 MB of ISS eigenvalues got slower through the double buffer, 190 MB of neighbour lists 2x faster)
         PCR_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCR_HIP(ctx, pcr_sync(ctx->stream));
         return PCR_OK;
     }
     if (!ctx->h_down) {
@@ -166,7 +235,7 @@ int pcr_d2h_staged(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t byt
     }
     if (!ctx->h_down) {
         PCR_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCR_HIP(ctx, pcr_sync(ctx->stream));
         return PCR_OK;
     }
     const size_t half = ctx->h_down_half;
@@ -197,7 +266,7 @@ int pcr_d2h_staged(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t byt
     for (int w = 0; w < W; ++w) th[w] = std::thread(worker, w);
     hipError_t e = hipMemcpyAsync(pin, dev_src, chunk_bytes(0), hipMemcpyDeviceToHost, ctx->stream);
     for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
-        e = hipStreamSynchronize(ctx->stream);   // chunk c is in its half
+        e = pcr_sync(ctx->stream);   // chunk c is in its half
         if (e != hipSuccess) break;
         landed.store(c + 1, std::memory_order_release);
         if (c + 1 < n_chunks) {
@@ -227,7 +296,23 @@ int pcr_search_stats(pcr_ctx* c, int64_t out[4]) {
     int rc = pcr_brute_last_fallback(c, &fb);
     if (rc) return rc;
     out[0] = fb;
-    out[1] = out[2] = out[3] = 0;
+    out[1] = c->arena_grow_count;
+    out[2] = (int64_t)c->arena_grow_us;
+    out[3] = (int64_t)c->arenas.size();
+    return PCR_OK;
+}
+
+int pcr_icp_pass_log(pcr_ctx* c, int max_n, double* tile_us, double* drain_us, int64_t* items, int* n_out, double host_us[6]) {
+    if (!c || !n_out || max_n < 0) return PCR_E_INVALID;
+    const int n = c->pass_log_n < max_n ? c->pass_log_n : max_n;
+    for (int k = 0; k < n; ++k) {
+        if (tile_us) tile_us[k] = c->pass_log[0][k];
+        if (drain_us) drain_us[k] = c->pass_log[1][k];
+        if (items) items[k] = (int64_t)c->pass_log[2][k];
+    }
+    *n_out = c->pass_log_n;
+    if (host_us)
+        for (int k = 0; k < 6; ++k) host_us[k] = c->pass_host_us[k];
     return PCR_OK;
 }
 
@@ -240,7 +325,7 @@ int pcr_timer_start(pcr_ctx* c) {
 int pcr_timer_stop_ms(pcr_ctx* c, double* ms) {
     if (!c || !ms) return PCR_E_INVALID;
     PCR_HIP(c, hipEventRecord(c->ev3, c->stream));
-    PCR_HIP(c, hipEventSynchronize(c->ev3));
+    PCR_HIP(c, pcr_event_sync(c->ev3));
     float f = 0;
     PCR_HIP(c, hipEventElapsedTime(&f, c->ev2, c->ev3));
     *ms = f;
@@ -255,7 +340,7 @@ void pcr_prof_mark(pcr_ctx* ctx, int k) {
 
 void pcr_prof_finish(pcr_ctx* ctx) {
     if (!ctx->profile) return;
-    hipEventSynchronize(ctx->pev[4]);
+    pcr_event_sync(ctx->pev[4]);
     for (int i = 0; i < 4; ++i) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->pev[i], ctx->pev[i + 1]) == hipSuccess) ctx->prof_ms[i] += ms;
@@ -287,7 +372,10 @@ int pcr_dev_alloc(pcr_ctx* ctx, size_t bytes, void** out) {
     if (ctx->arenas.empty() || ctx->arena_used + bytes > ctx->arena_cap) {
         const size_t cap = bytes > PCR_ARENA_BYTES ? bytes : PCR_ARENA_BYTES;
         void* base = nullptr;
+        const auto t_a = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&base, cap);
+        ctx->arena_grow_count += 1;   // (pcr_search_stats: a call that had to grow an arena -- milliseconds, on the host, with the stream idle -- says so)
+        ctx->arena_grow_us += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_a).count() / 1e3;
         if (e != hipSuccess) {
             ctx->last_error = std::string("hipMalloc(arena): ") + hipGetErrorString(e);
             return PCR_E_NOMEM;
@@ -332,7 +420,7 @@ int pcr_ctx_lanes(pcr_ctx* ctx, int lanes) {
 int pcr_ensure_scratch(pcr_ctx* ctx, size_t partial_bytes) {
     if (ctx->d_partials_bytes >= partial_bytes) return PCR_OK;
     if (ctx->d_partials) {
-        hipStreamSynchronize(ctx->stream);
+        pcr_sync(ctx->stream);
         hipFree(ctx->d_partials);
         ctx->d_partials = nullptr;
         ctx->d_partials_bytes = 0;
@@ -501,7 +589,7 @@ static int upload_impl(pcr_ctx* ctx, const S* xyz, int64_t n, int64_t stride, pc
                        (unsigned long long*)(ctx->d_counters + 16), h_box_dev);
     PCR_HIP(ctx, hipGetLastError());
     // the staging buffer is reused by the next upload (and an unstaged copy reads caller-owned memory): finish before returning
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_HIP(ctx, pcr_sync(ctx->stream));
     {
         // (S -> double is exact, so this is the box a binary64 reduction over the records gives; a NaN or an infinity shows up as
         // a non-finite corner: no box then, the device reduction of pcr_cloud_bbox decides later, as before)
@@ -561,7 +649,7 @@ int pcr_cloud_download_f64(pcr_ctx* ctx, const pcr_cloud* c, double* out) {
     hipLaunchKernelGGL(pack_xyz_kernel, dim3(grid), dim3(block), 0, ctx->stream, (const pcr_pt*)c->d, (long long)c->n, d_tmp);
     PCR_HIP(ctx, hipGetLastError());
     PCR_HIP(ctx, hipMemcpyAsync(out, d_tmp, sizeof(double) * 3 * c->n, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_HIP(ctx, pcr_sync(ctx->stream));
     pcr_dev_free(ctx, d_tmp, sizeof(double) * 3 * c->n);
     return PCR_OK;
 }

@@ -650,10 +650,9 @@ int fpfh_device(pcr_ctx* ctx, const pcr_cloud* cloud, const double* d_normals, d
 
 int read_fail(pcr_ctx* ctx) {   // synchronises
     int fail = 0;
-    hipError_t e = hipMemcpyAsync(&fail, fail_word(ctx), sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(fail_word(ctx), 0, sizeof(int), ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
+    const int rc = pcr_d2h_small(ctx, &fail, fail_word(ctx), sizeof(int));   // (synchronises)
+    if (rc) return rc;
+    if (fail) hipMemsetAsync(fail_word(ctx), 0, sizeof(int), ctx->stream);
     if (fail) { ctx->last_error = "more than 1024 equidistant neighbours"; return PCR_E_UNSUPPORTED; }
     return PCR_OK;
 }
@@ -700,18 +699,23 @@ int ransac_device(pcr_ctx* ctx, const pcr_pt* d_src, const pcr_pt* d_tgt, const 
     a.src = d_src; a.tgt = d_tgt; a.corr = d_corr;
     a.seed = prm->seed; a.edge_sim = prm->edge_similarity; a.max_dist = prm->max_distance; a.check_distance = prm->check_distance;
     a.max_iteration = prm->max_iteration; a.confidence = prm->confidence;
-    for (long long done = 0; done < prm->max_iteration;) {
-        const long long want = done == 0 ? FIRST : BATCH;
-        const int nb = (int)((prm->max_iteration - done) < want ? (prm->max_iteration - done) : want);
-        a.first_iter = (int)done; a.n_iter = nb;
-        hipLaunchKernelGGL(ransac_kernel, dim3(nb), dim3(64), 0, ctx->stream, a, (const ransac_state*)st, dinl.as<int>(), derr.as<double>(), dT.as<double>());
-        hipLaunchKernelGGL(ransac_walk_kernel, dim3(1), dim3(64), 0, ctx->stream, a, st, (const int*)dinl.as<int>(), (const double*)derr.as<double>(), (const double*)dT.as<double>());
-        done += nb;
-    }
-    PCR_HIP(ctx, hipGetLastError());
+    // the first two batches (20 480 iterations) go out together -- most registrations exit within the first thousand --, then
+    // the state is looked at; what is left of the budget follows in one go (batches behind a stop return at once)
     ransac_state h;
-    PCR_HIP(ctx, hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    long long done = 0;
+    for (int round = 0; done < prm->max_iteration; ++round) {
+        for (int b = 0; done < prm->max_iteration && (round > 0 || b < 2); ++b) {
+            const long long want = done == 0 ? FIRST : BATCH;
+            const int nb = (int)((prm->max_iteration - done) < want ? (prm->max_iteration - done) : want);
+            a.first_iter = (int)done; a.n_iter = nb;
+            hipLaunchKernelGGL(ransac_kernel, dim3(nb), dim3(64), 0, ctx->stream, a, (const ransac_state*)st, dinl.as<int>(), derr.as<double>(), dT.as<double>());
+            hipLaunchKernelGGL(ransac_walk_kernel, dim3(1), dim3(64), 0, ctx->stream, a, st, (const int*)dinl.as<int>(), (const double*)derr.as<double>(), (const double*)dT.as<double>());
+            done += nb;
+        }
+        PCR_HIP(ctx, hipGetLastError());
+        if ((rc = pcr_d2h_small(ctx, &h, st, sizeof(h)))) return rc;   // (synchronises)
+        if (h.stop) break;
+    }
     if (h.m < 3) return PCR_E_TOO_FEW_ASSOC;
     res->iterations = (int)h.done;
     res->n_valid = (int)h.n_valid;
@@ -770,7 +774,7 @@ int pcr_preprocess(pcr_ctx* ctx, const pcr_cloud* cloud, double voxel_size, doub
     if (rc == PCR_OK) rc = hybrid_normals_device(ctx, p->down, normal_radius, normal_max_nn, 1, nullptr, p->normals);
     if (rc == PCR_OK) rc = fpfh_device(ctx, p->down, p->normals, fpfh_radius, fpfh_max_nn, p->fpfh);
     if (rc == PCR_OK) rc = read_fail(ctx);
-    if (rc != PCR_OK) { hipStreamSynchronize(ctx->stream); pcr_prep_free(ctx, p); return rc; }
+    if (rc != PCR_OK) { pcr_sync(ctx->stream); pcr_prep_free(ctx, p); return rc; }
     *out = p;
     return PCR_OK;
 }
@@ -781,7 +785,7 @@ int pcr_prep_download(pcr_ctx* ctx, const pcr_prep* p, double* points, double* n
     if (points) { const int rc = pcr_cloud_download_f64(ctx, p->down, points); if (rc) return rc; }
     if (normals) PCR_HIP(ctx, hipMemcpyAsync(normals, p->normals, sizeof(double) * 3 * p->n, hipMemcpyDeviceToHost, ctx->stream));
     if (features) PCR_HIP(ctx, hipMemcpyAsync(features, p->fpfh, sizeof(double) * 33 * p->n, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_HIP(ctx, pcr_sync(ctx->stream));
     return PCR_OK;
 }
 
@@ -801,7 +805,19 @@ int pcr_global_registration(pcr_ctx* ctx, const pcr_prep* source, const pcr_prep
     int* const d_m = corr.as<int>() + 2 * na;
     hipLaunchKernelGGL(corr_build_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int*)ij.as<int>(), (const int*)ji.as<int>(), (int)na, mutual_filter ? 1 : 0, 9,
                        corr.as<int>(), d_m);
-    return ransac_device(ctx, source->down->d, target->down->d, corr.as<int>(), d_m, prm, res);
+    // the sampled records by ROW: the down-sampled clouds are written in row order, but a caller that has used one as the query
+    // cloud of a search since (pcr_nn1 lays its queries out along the index's curve, in place) has re-ordered it
+    const pcr_pt *s_rows = source->down->d, *t_rows = target->down->d;
+    dev_buf s_tmp(ctx), t_tmp(ctx);
+    if (source->down->morton_sorted) {
+        if ((rc = s_tmp.alloc(sizeof(pcr_pt) * na)) || (rc = pcr_cloud_rows(ctx, source->down, s_tmp.as<pcr_pt>()))) return rc;
+        s_rows = s_tmp.as<pcr_pt>();
+    }
+    if (target->down->morton_sorted) {
+        if ((rc = t_tmp.alloc(sizeof(pcr_pt) * nb)) || (rc = pcr_cloud_rows(ctx, target->down, t_tmp.as<pcr_pt>()))) return rc;
+        t_rows = t_tmp.as<pcr_pt>();
+    }
+    return ransac_device(ctx, s_rows, t_rows, corr.as<int>(), d_m, prm, res);
 }
 
 int pcr_normals_hybrid(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int max_nn, int orient, const double viewpoint[3], double* normals_out) {
@@ -847,7 +863,7 @@ int pcr_feature_match(pcr_ctx* ctx, const double* queries, int64_t nq, const dou
     if ((rc = feature_match_device(ctx, a.as<double>(), nq, b.as<double>(), nt, dim, di.as<int>(), dd.as<double>()))) return rc;
     PCR_HIP(ctx, hipMemcpyAsync(idx_out, di.p, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
     if (d2_out) PCR_HIP(ctx, hipMemcpyAsync(d2_out, dd.p, sizeof(double) * nq, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_HIP(ctx, pcr_sync(ctx->stream));
     return PCR_OK;
 }
 

@@ -227,7 +227,7 @@ int pcr_bbox(pcr_ctx* ctx, const pcr_pt* pts, long long n, double lo[3], double 
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, ctx->stream, pts, n, d_part);
     std::vector<double> h_part(6 * nb);
     PCR_HIP(ctx, hipMemcpyAsync(h_part.data(), d_part, sizeof(double) * 6 * nb, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_HIP(ctx, pcr_sync(ctx->stream));
     pcr_dev_free(ctx, d_part, sizeof(double) * 6 * nb);
     for (int k = 0; k < 3; ++k) { lo[k] = DBL_MAX; hi[k] = -DBL_MAX; }
     for (int b = 0; b < nb; ++b)
@@ -410,7 +410,7 @@ int pcr_grid_build(pcr_ctx* ctx, const pcr_cloud* tgt, double cell, pcr_index* i
     const bool k32 = end_bit <= 32;
     rc = k32 ? morton_sort_records<unsigned int>(ctx, tgt->d, n, lo, inv, end_bit, levels, idx->sorted, &sc)
              : morton_sort_records<unsigned long long>(ctx, tgt->d, n, lo, inv, end_bit, levels, idx->sorted, &sc);
-    if (rc == PCR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->last_error = "hipStreamSynchronize (index build)"; rc = PCR_E_HIP; }
+    if (rc == PCR_OK && pcr_sync(ctx->stream) != hipSuccess) { ctx->last_error = "hipStreamSynchronize (index build)"; rc = PCR_E_HIP; }
     if (rc == PCR_OK) {
         unsigned int h_counts[PCR_MAX_LEVELS];
         memcpy(h_counts, ctx->h_pinned, sizeof(h_counts));

@@ -26,13 +26,17 @@
 // box distance exceeds a bound that is itself >= the final answer, so every stage returns the exact nearest neighbour
 // (lowest index on ties).
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include "pcr_grid_dev.h"
 #include "pcr_icp_step.h"
 
-constexpr unsigned int HARD_SCAN_T = 192;   // the hard stage scans cells up to this size, descends into bigger ones
+#ifndef PCR_HARD_SCAN_T
+#define PCR_HARD_SCAN_T 192
+#endif
+constexpr unsigned int HARD_SCAN_T = PCR_HARD_SCAN_T;   // the hard stage scans cells up to this size, descends into bigger ones
 constexpr int HARD_STACK = 160;
 constexpr long long ID_NONE = 0x7fffffffffffffffll;
 // The unresolved queries go to H_NLIST sub-lists (tile t appends to list t % H_NLIST): one returning atomic per tile on
@@ -1014,7 +1018,14 @@ __device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard
         return top + 1;  // not even the top level's block covers the ball
     };
     have_cand = have_cand || __any(bd2 < DBL_MAX);
+#ifndef PCR_HARD_START_MAX
+#define PCR_HARD_START_MAX 99
+#endif
+    // (PCR_HARD_START_MAX: the search never STARTS above this level even when the candidate's ball asks for it -- in a dense cloud the
+    // true neighbour is centimetres away while the candidate, last pass's neighbour seen from the moved query, may be decimetres
+    // away: the block at a fine level shrinks the ball before the coarse cells it would have touched are split one by one)
     int s_level = clamped ? top + 1 : (have_cand ? level_for(bound2, 0) : 0);
+    if (s_level <= top && s_level > PCR_HARD_START_MAX) s_level = PCR_HARD_START_MAX;
     s_level0 = s_level;
     int sp = 0;  // wave-uniform stack pointer
     while (s_level <= top) {
@@ -1217,7 +1228,16 @@ struct pass_args {
     pcr_icp_loop_args la;
     unsigned int* tile_cost;              // [waves]: points every tile staged in the last pass (issue priority of this one)
     unsigned int pass_id;                 // passes enqueued so far in this ICP call
+    unsigned long long* host_block;       // (or null) the context's pinned landing block as the device sees it: the wave that finishes the LAST pass
+    unsigned int notify;                  // of a chunk (notify != 0), or the pass that stops the loop, writes state + log + flag there itself
+    unsigned int* plog;                   // per-pass log of the call (or null): s_memrealtime stamps, 100 MHz, low 32 bits -- [pass] end of the pass,
+                                          // [256 + pass] start of the drain launch (0: one-launch pass), [512 + pass] queue items, [768] start of the call
 };
+constexpr int PASS_LOG_WORDS = 3 * PCR_ICP_MAX_LOG + 8;   // 32-bit words
+// the context's mapped landing block (8 KiB): loop state | pass log | ... | completion flag (last word)
+constexpr size_t HOST_LOG_OFF = (sizeof(pcr_icp_dev_state) + 63) & ~(size_t)63;
+constexpr size_t HOST_FLAG_OFF = 8192 - 8;
+static_assert(HOST_LOG_OFF + 4 * PASS_LOG_WORDS <= HOST_FLAG_OFF, "state + pass log + flag fit the landing block");
 __host__ __device__ static inline unsigned int pass_item_cap(long long nq) {   // room for every query of the group's tiles
     const long long tiles = (nq + WT_Q - 1) / WT_Q + 4;
     return (unsigned int)(((tiles + PASS_GROUPS - 1) / PASS_GROUPS) * (WT_Q + 1));   // + the poison range
@@ -1346,8 +1366,29 @@ __device__ __forceinline__ static void pass_finish(const pcr_grid_view& gv, pass
     }
     wave_sync();
     if (dbg && lane == 0) dbg[(1 << 19) - 2] = __builtin_amdgcn_s_memrealtime();
+    if (A.plog && lane == 0 && A.pass_id < (unsigned int)PCR_ICP_MAX_LOG) A.plog[A.pass_id] = (unsigned int)__builtin_amdgcn_s_memrealtime();
     if (lane < HEAD_WORDS) reinterpret_cast<unsigned long long*>(A.st)[lane] = reinterpret_cast<const unsigned long long*>(head)[lane];
     if (dbg && lane == 0) dbg[(1 << 19) - 1] = __builtin_amdgcn_s_memrealtime();
+    // The host's copy, written from HERE when the host waits for this pass (the last one of its chunk, or the one that stops the
+    // loop): on this pool whatever small operation follows the last big kernel of a call -- a copy, a one-block kernel, an event --
+    // starts 16-45 ms late every 10th-30th call, so the call's result must not depend on one.  State head
+    // from LDS, the logs from memory (this pass's own entries were stored by lane 0 above: acknowledged first), the pass log, then
+    // a system-scope release and the flag the host polls.
+    if (A.host_block) {
+        const int stop_now = reinterpret_cast<const pcr_icp_dev_state*>(head)->stop;   // (LDS: the same in every lane)
+        if (A.notify || stop_now) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_sync();
+            constexpr int STATE_WORDS = (int)(sizeof(pcr_icp_dev_state) / 8);
+            if (lane < HEAD_WORDS) A.host_block[lane] = reinterpret_cast<const unsigned long long*>(head)[lane];
+            for (int w = HEAD_WORDS + lane; w < STATE_WORDS; w += 64) A.host_block[w] = ld_dev(reinterpret_cast<const unsigned long long*>(A.st) + w);
+            if (A.plog)
+                for (int w = lane; w < PASS_LOG_WORDS / 2; w += 64) A.host_block[HOST_LOG_OFF / 8 + w] = ld_dev(reinterpret_cast<const unsigned long long*>(A.plog) + w);
+            __threadfence_system();
+            wave_sync();
+            if (lane == 0) __hip_atomic_store(A.host_block + HOST_FLAG_OFF / 8, (unsigned long long)A.pass_id + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 #ifndef PCR_PASS_DIAG
@@ -1355,7 +1396,8 @@ __device__ __forceinline__ static void pass_finish(const pcr_grid_view& gv, pass
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCR_WT_WAVES, 8)))
 grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt* __restrict__ q, long long nq, double max_d2, int xcd_remap,
-                 unsigned int pcap, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg_arg, int use_prev, int inline_queue, pass_args A) {
+                 unsigned int pcap_arg, unsigned int pcap_busy, unsigned int* __restrict__ res_pos, unsigned long long* __restrict__ dbg_arg, int use_prev, int inline_queue,
+                 pass_args A) {
     // the kernel's own stamps and counters (scripts/pass_stamps.py, wt_stamps.py, hard_stamps.py) are compiled in by -DPCR_PASS_DIAG=1 only:
     // as a run-time switch they kept ~14 scalar registers alive through the whole kernel, which spills scalars into vector lanes as it is
     unsigned long long* const dbg = PCR_PASS_DIAG ? dbg_arg : nullptr;
@@ -1368,6 +1410,18 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     wt_pre P;
     wtile_preload(tile, lane, q, nq, res_pos, use_prev ? A.prev_xyz : nullptr, P);
     const unsigned int last_cost = use_prev ? A.tile_cost[tile] : 0u;
+    // Staging cap of this pass's tiles.  A launch of several wave generations does not end with its slowest tile but with the sum of
+    // all of them, and a query a tile leaves open costs a whole wave of the drain launch 10-30 us: while many queries overflow their
+    // tiles -- the unseeded first pass, and the passes of a source that still moves by decimetres per iteration in a cloud whose
+    // neighbours are centimetres apart (1 M x 1 M, eight overlapping frames, 0.8 m off: 200 000 queue items per pass, every one "too
+    // many points in the box") -- the tiles stage up to pcap_busy points (items 203 000 -> 76 000, drain 1.46 -> 0.73 ms for 0.3 ms more
+    // in the tiles); once the last pass's queue was short (< 1/16 of the queries) the small cap is the faster one again.
+    unsigned int pcap = pcap_arg;
+    if (pcap_busy > pcap_arg && A.plog) {
+        const unsigned int prev_items = A.pass_id > 0 && A.pass_id <= (unsigned int)PCR_ICP_MAX_LOG ? A.plog[2 * PCR_ICP_MAX_LOG + A.pass_id - 1] : 0xffffffffu;
+        if ((unsigned long long)prev_items * 16ull > (unsigned long long)nq) pcap = pcap_busy;
+        pcap = (unsigned int)__builtin_amdgcn_readfirstlane((int)pcap);
+    }
     const pcr_xform x = A.st->x;
     if (A.st->stop) return;
     // The launch ends with its slowest tiles (several staging rounds in the densest part of the scan), and while all tiles run the
@@ -1650,6 +1704,7 @@ grid_drain_kernel(pcr_grid_view gv, double max_d2, unsigned int* __restrict__ re
     __shared__ pass_lds s_lds[4];
     if (A.st->stop) return;
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_rt_start = __builtin_amdgcn_s_memrealtime();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     pass_lds* L = &s_lds[wave];
     // exclusive prefix of the groups' item counts (lanes 0..PASS_GROUPS-1 hold one group each; written by the previous launch)
@@ -1658,6 +1713,12 @@ grid_drain_kernel(pcr_grid_view gv, double max_d2, unsigned int* __restrict__ re
     unsigned int total = 0;
     const unsigned int l_exc = wave_excl_scan_u32(l_cnt, lane, &total);
     const unsigned int n_waves = gridDim.x * 4;
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[(1 << 19) - 8] = total;   // diagnostics (PCR_DEBUG_STAMPS): items of this pass
+    if (A.plog && blockIdx.x == 0 && threadIdx.x == 0 && A.pass_id < (unsigned int)PCR_ICP_MAX_LOG) {
+        // (launched behind the tile kernel on the same stream: the first wave of this launch starts when that one has ended)
+        A.plog[PCR_ICP_MAX_LOG + A.pass_id] = (unsigned int)t_rt_start | 1u;
+        A.plog[2 * PCR_ICP_MAX_LOG + A.pass_id] = total;
+    }
     for (unsigned int w_i = blockIdx.x * 4 + wave; w_i < total; w_i += n_waves) {
         const int grp = (int)__ffsll((long long)__ballot(lane < PASS_GROUPS && l_exc <= w_i && w_i < l_exc + l_cnt)) - 1;   // exactly one group holds item w_i
         const unsigned int idx = w_i - (unsigned int)__builtin_amdgcn_readlane((int)l_exc, grp);
@@ -1880,7 +1941,7 @@ static void grid_scratch_free(pcr_ctx* ctx, grid_scratch* sc) {
     if (sc->items) pcr_dev_free(ctx, sc->items, 32 * (size_t)PASS_GROUPS * pass_item_cap(sc->nq));
     if (sc->tile_cost) pcr_dev_free(ctx, sc->tile_cost, sizeof(unsigned int) * (size_t)((sc->nq + 4 * WT_Q - 1) / (4 * WT_Q)) * 4);
     sc->tile_cost = nullptr;
-    if (sc->acc) pcr_dev_free(ctx, sc->acc, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS));
+    if (sc->acc) pcr_dev_free(ctx, sc->acc, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS + PASS_LOG_WORDS / 2));
     sc->res_pos = nullptr; sc->res_d2 = nullptr; sc->hard_list = nullptr; sc->prev_xyz = nullptr; sc->items = nullptr; sc->acc = nullptr;
 }
 
@@ -1890,6 +1951,10 @@ static unsigned int wtile_point_cap(const pcr_ctx* ctx, int64_t nq) {
     static const int wt_rounds_env = getenv("PCR_WT_ROUNDS") ? atoi(getenv("PCR_WT_ROUNDS")) : 0;
     const int nblocks = (int)((nq + 63) / 64);
     return (unsigned int)WT_PR * (wt_rounds_env > 0 ? wt_rounds_env : (nblocks > 8 * ctx->cu_count ? WT_ROUNDS_LARGE : WT_ROUNDS_SMALL));
+}
+static unsigned int wtile_busy_cap() {   // PCR_WT_ROUNDS_BUSY: staging rounds of a tile while the queue of the last pass was long (see grid_pass_kernel)
+    static const int env = getenv("PCR_WT_ROUNDS_BUSY") ? atoi(getenv("PCR_WT_ROUNDS_BUSY")) : 0;
+    return (unsigned int)WT_PR * (unsigned int)(env > 0 ? env : 48);
 }
 static int wtile_xcd_remap() {
     static const int xcd_remap = getenv("PCR_TILE_XCD") ? atoi(getenv("PCR_TILE_XCD")) : 1;
@@ -1985,7 +2050,7 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         return PCR_OK;
     }
     if ((rc = pcr_ctx_lanes(ctx, lanes))) return rc;
-    if (!was_sorted) PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sort ran on the main stream
+    if (!was_sorted) PCR_HIP(ctx, pcr_sync(ctx->stream));  // the sort ran on the main stream
     grid_scratch sc[PCR_MAX_LANES];
     int grids[PCR_MAX_LANES];
     const int64_t per = ((nq + lanes - 1) / lanes + 1023) / 1024 * 1024;
@@ -2008,7 +2073,7 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     }
     hipError_t e = hipGetLastError();
     for (int l = 0; l < used; ++l) {
-        const hipError_t es = hipStreamSynchronize(lanes == 1 ? ctx->stream : ctx->lane_stream[l]);
+        const hipError_t es = pcr_sync(lanes == 1 ? ctx->stream : ctx->lane_stream[l]);
         if (e == hipSuccess) e = es;
         grid_scratch_free(ctx, &sc[l]);
     }
@@ -2030,7 +2095,7 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     // hand the sum over the way the single-lane pass does (the caller reads h_pinned, or copies d_moments)
     if (d_moments == ctx->h_pinned) memcpy(ctx->h_pinned, m, sizeof(m));
     else PCR_HIP(ctx, hipMemcpyAsync(d_moments, m, sizeof(m), hipMemcpyHostToDevice, ctx->stream));
-    if (d_moments != ctx->h_pinned) PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (d_moments != ctx->h_pinned) PCR_HIP(ctx, pcr_sync(ctx->stream));
     return PCR_OK;
 }
 
@@ -2046,7 +2111,8 @@ int pcr_grid_icp_pass(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
 struct pass_T0 { double v[16]; };
 __global__ void __launch_bounds__(256)
 pass_init_kernel(unsigned long long* __restrict__ zero_p, unsigned int zero_n, unsigned long long* __restrict__ ones_p, unsigned long long ones_n,
-                 pcr_icp_dev_state* __restrict__ st, pass_T0 T0) {
+                 pcr_icp_dev_state* __restrict__ st, pass_T0 T0, unsigned int* __restrict__ plog, unsigned long long* __restrict__ host_started) {
+    if (host_started && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(host_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // "the call's first kernel runs"
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < ones_n; i += stride) ones_p[i] = ~0ull;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += stride) zero_p[i] = 0ull;
@@ -2067,6 +2133,7 @@ pass_init_kernel(unsigned long long* __restrict__ zero_p, unsigned int zero_n, u
         for (int i = 0; i < 16; ++i) st->T_total[i] = (i % 5 == 0) ? 1.0 : 0.0;
         for (int i = 0; i < 9; ++i) st->V[i] = (i % 4 == 0) ? 1.0 : 0.0;
         st->first = 1;
+        if (plog) plog[3 * PCR_ICP_MAX_LOG] = (unsigned int)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -2099,6 +2166,9 @@ struct loop_guard {
 int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_icp_params* params, const double T0[16],
                       pcr_icp_result* res) {
     const loop_guard in_flight(ctx->device);
+    const auto h_t0 = std::chrono::steady_clock::now();   // host-side phases of the call (pcr_icp_pass_log): where a slow call spent its time
+    auto h_us = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a).count() / 1e3; };
+    for (double& v : ctx->pass_host_us) v = 0.0;
     const char* const wait_s = getenv("PCR_PASS_INLINE");   // read per call: the tests switch it
     const int wait_env = wait_s ? atoi(wait_s) : -1;   // 0 / 1 force a variant; default: inline when alone on the device
     const bool gated = (params->max_d2 > 0) && std::isfinite(params->max_d2);
@@ -2122,7 +2192,7 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         if (!pcr_pass_fixed_scale(idx->lo, idx->hi, nq, params->max_d2, &sc_f, &sc_i)) fused = false;   // absurd extents: keep the binary64 slabs
         else {
             pa.cap = pass_item_cap(nq);
-            if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS), (void**)&sc.acc)) ||
+            if ((rc = pcr_dev_alloc(ctx, sizeof(unsigned long long) * (ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS + PASS_LOG_WORDS / 2), (void**)&sc.acc)) ||
                 (rc = pcr_dev_alloc(ctx, sizeof(unsigned int) * (size_t)((nq + 4 * WT_Q - 1) / (4 * WT_Q)) * 4, (void**)&sc.tile_cost)) ||
                 (rc = pcr_dev_alloc(ctx, 32 * (size_t)PASS_GROUPS * pa.cap, (void**)&sc.items))) {
                 grid_scratch_free(ctx, &sc);
@@ -2132,6 +2202,7 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             pa.tile_cost = sc.tile_cost;
             pa.acc = sc.acc;
             pa.sync = sc.acc + ACC_SETS * PCR_NMOM;
+            pa.plog = (unsigned int*)(sc.acc + ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS);   // (zeroed with the accumulators by pass_init_kernel)
             pa.prev_xyz = (wt_xyz*)sc.prev_xyz;
             pa.scale = sc_f;
             pa.inv_scale = sc_i;
@@ -2158,14 +2229,24 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
     la.max_iter = params->max_iter; la.min_iter = params->min_iter;
     la.compat = params->mode == PCR_ICP_COMPAT_MAIN; la.r_metric = params->r_metric;
     la.r_thres = params->r_thres; la.t_thres = params->t_thres;
+    volatile unsigned long long* const h_flag = (volatile unsigned long long*)((char*)ctx->h_state + HOST_FLAG_OFF);
+    static const bool no_notify = getenv("PCR_ICP_NO_NOTIFY") != nullptr;   // A/B: read the state back by kernels behind the chunk instead
+    if (fused && !no_notify) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, ctx->h_state, 0) == hipSuccess) pa.host_block = (unsigned long long*)dp;
+        *h_flag = 0ull;   // (the stream is idle: the previous call waited for its own flag)
+        h_flag[-1] = 0ull;   // "the call's first kernel runs"
+    }
     hipError_t e = hipSuccess;
+    ctx->pass_host_us[0] = h_us(h_t0);   // set-up: lay-out check, scratch from the arena
     if (fused) {
         pass_T0 t0;
         for (int i = 0; i < 16; ++i) t0.v[i] = T0[i];
         const unsigned long long ones_n = 4ull * PASS_GROUPS * pa.cap;
         const int ib = (int)((ones_n + 256 * 8 - 1) / (256 * 8));
         hipLaunchKernelGGL(pass_init_kernel, dim3(ib < 1 ? 1 : (ib > 1024 ? 1024 : ib)), dim3(256), 0, ctx->stream, sc.acc,
-                           (unsigned int)(ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS), sc.items, ones_n, d_st, t0);
+                           (unsigned int)(ACC_SETS * PCR_NMOM + PASS_SYNC_WORDS + PASS_LOG_WORDS / 2), sc.items, ones_n, d_st, t0, pa.plog,
+                           pa.host_block ? pa.host_block + HOST_FLAG_OFF / 8 - 1 : (unsigned long long*)nullptr);
         e = hipGetLastError();
     } else e = hipMemcpyAsync(d_st, h_st, sizeof(*h_st), hipMemcpyHostToDevice, ctx->stream);
     pa.st = d_st;
@@ -2192,11 +2273,14 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
             const int inline_queue = wait_env >= 0 ? wait_env : ((one_generation && !ctx->shared_device && in_flight.n.load(std::memory_order_relaxed) == 1) ? 1 : 0);
             if (fused) {
                 if (ctx->profile) pcr_prof_mark(ctx, 0);
-                if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * ((1 << 16) + 8 * (size_t)((nq + 63) / 64)), ctx->stream);
+                if (ctx->d_debug) hipMemsetAsync(ctx->d_debug, 0, sizeof(unsigned long long) * (inline_queue ? ((1 << 16) + 8 * (size_t)((nq + 63) / 64)) : ((size_t)1 << 19)), ctx->stream);
                 const int wblocks = (int)((nq + 4 * WT_Q - 1) / (4 * WT_Q));
                 pa.pass_id = (unsigned int)(enq + c);
+                pa.notify = c == chunk - 1 ? 1u : 0u;
+                // (the busy cap only where the drain launch exists and logs its item counts: two-launch passes)
+                const unsigned int cap_n = wtile_point_cap(ctx, nq), cap_busy = (!inline_queue && cap_n > (unsigned int)(WT_PR * WT_ROUNDS_SMALL)) ? wtile_busy_cap() : cap_n;
                 hipLaunchKernelGGL(grid_pass_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, (const pcr_grid_view*)idx->d_view, idx->view, qc->d, (long long)nq,
-                                   params->max_d2, wtile_xcd_remap(), wtile_point_cap(ctx, nq), sc.res_pos, ctx->d_debug, use_prev ? 1 : 0, inline_queue, pa);
+                                   params->max_d2, wtile_xcd_remap(), cap_n, cap_busy, sc.res_pos, ctx->d_debug, use_prev ? 1 : 0, inline_queue, pa);
                 if (ctx->profile) pcr_prof_mark(ctx, 1);
                 if (!inline_queue) {
                     // 8 blocks of 4 waves per CU, like the stand-alone hard stage
@@ -2222,14 +2306,57 @@ int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const p
         }
         enq += chunk;
         if (rc) break;
-        e = hipMemcpyAsync(h_st, d_st, sizeof(*h_st), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (ctx->pass_host_us[1] == 0.0) ctx->pass_host_us[1] = h_us(h_t0) - ctx->pass_host_us[0];   // enqueueing the first chunk of passes
+        const auto h_tw = std::chrono::steady_clock::now();
+        if (pa.host_block) {
+            // the finishing wave of the chunk's last pass (or of the pass that stopped the loop) has written state, log and flag
+            bool seen = false;
+            for (unsigned int spins = 0;; ++spins) {
+                if (ctx->pass_host_us[4] == 0.0 && h_flag[-1] != 0ull) ctx->pass_host_us[4] = h_us(h_t0);   // the call's first kernel has started
+                const unsigned long long f = __atomic_load_n((const unsigned long long*)h_flag, __ATOMIC_ACQUIRE);
+                if (f >= (unsigned long long)enq || (f > 0 && h_st->stop)) { seen = true; break; }
+                if ((spins & 255u) == 255u && h_us(h_tw) > 2e6) break;
+                __builtin_ia32_pause();
+            }
+            ctx->pass_host_us[5] = h_us(h_tw);
+            if (!seen) {   // never seen within two seconds: ask the runtime, read the state back the slow way
+                e = pcr_sync(ctx->stream);
+                if (e == hipSuccess && pcr_d2h_small(ctx, h_st, d_st, sizeof(*h_st)) != PCR_OK) e = hipErrorUnknown;
+            }
+        } else {
+            hipEventRecord(ctx->ev3, ctx->stream);   // behind the chunk's last kernel, in front of the read-back (pass_host_us[4])
+            if (pcr_d2h_small_enqueue(ctx, h_st, d_st, sizeof(*h_st)) != PCR_OK) e = hipErrorUnknown;
+            if (e == hipSuccess && fused && pcr_d2h_small_enqueue(ctx, (char*)ctx->h_state + HOST_LOG_OFF, pa.plog, 4 * PASS_LOG_WORDS) != PCR_OK) e = hipErrorUnknown;
+            double flag_us = 0.0;
+            if (e == hipSuccess && pcr_wait_flag(ctx, &flag_us) != PCR_OK) e = hipErrorUnknown;   // (by reading memory: not through the runtime)
+            ctx->pass_host_us[5] = flag_us;
+            { float ms = 0; if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev3) == hipSuccess) ctx->pass_host_us[4] = 1e3 * ms; }   // call start .. last kernel of this chunk, by HIP events
+        }
+        ctx->pass_host_us[2] += h_us(h_tw);   // waiting for the device
         if (e != hipSuccess || h_st->stop) break;
         if (!ctx->profile) chunk *= 2;
     }
     if (e == hipSuccess) e = hipGetLastError();
+    ctx->pass_log_n = 0;
+    ctx->loop_dev_ms = 0.0;
+    if (e == hipSuccess && rc == PCR_OK && fused) {
+        const unsigned int* const lg = (const unsigned int*)((const char*)ctx->h_state + HOST_LOG_OFF);
+        const int np = h_st->passes < PCR_ICP_MAX_LOG ? h_st->passes : PCR_ICP_MAX_LOG;
+        unsigned int prev = lg[3 * PCR_ICP_MAX_LOG];
+        for (int k = 0; k < np; ++k) {
+            const unsigned int end = lg[k], ds = lg[PCR_ICP_MAX_LOG + k];
+            ctx->pass_log[0][k] = 0.01 * (double)(unsigned int)((ds ? ds : end) - prev);     // tile launch (one-launch pass: the whole pass), us
+            ctx->pass_log[1][k] = ds ? 0.01 * (double)(unsigned int)(end - ds) : 0.0;       // drain launch, us
+            ctx->pass_log[2][k] = (double)lg[2 * PCR_ICP_MAX_LOG + k];                      // queue items (two-launch passes)
+            prev = end;
+        }
+        ctx->pass_log_n = np;
+        // the loop's duration on the device, from the kernels' own clock: first kernel of the call .. end of its last pass
+        ctx->loop_dev_ms = np > 0 ? 1e-5 * (double)(unsigned int)(lg[np - 1] - lg[3 * PCR_ICP_MAX_LOG]) : 0.0;
+    }
     grid_scratch_free(ctx, &sc);
     pcr_dev_free(ctx, d_st, sizeof(pcr_icp_dev_state));
+    ctx->pass_host_us[3] = h_us(h_t0);   // the whole loop on the host
     if (rc) return rc;
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
     if (h_st->status == PCR_E_HIP) { ctx->last_error = "ICP pass: a wave gave up waiting on the work queue"; return PCR_E_HIP; }

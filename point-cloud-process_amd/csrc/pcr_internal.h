@@ -98,9 +98,13 @@ struct pcr_ctx {
     std::vector<blk> live;       // blocks handed out, with their TRUE capacity (a reused block may be larger than asked for)
     std::vector<void*> arenas;   // 256-MiB hipMalloc chunks the blocks are carved from
     size_t arena_cap = 0, arena_used = 0;
+    unsigned long long flag_seq = 0;   // pcr_wait_flag
+    long long arena_grow_count = 0;   // hipMalloc calls for arenas since the context was created, and the host time they took
+    double arena_grow_us = 0;
     // pinned host scratch for the per-iteration moment read-back
     double* h_pinned = nullptr;
-    void* h_state = nullptr;              // pinned 8-KiB staging buffer of the device-resident ICP state
+    void* h_state = nullptr;              // pinned, device-mapped 8-KiB landing block of the device-resident ICP state (+ its pass log)
+    void* h_small = nullptr;              // pinned, device-mapped landing block of pcr_d2h_small
     void* h_stage = nullptr;              // pinned staging buffer for uploads from pageable caller memory (grown on demand, <= 64 MiB)
     size_t h_stage_bytes = 0;
     void* h_down = nullptr;               // pinned double buffer for large device-to-host results (pcr_d2h_staged), 2 x h_down_half bytes
@@ -122,10 +126,41 @@ struct pcr_ctx {
     hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[4] = {0, 0, 0, 0};
     int prof_passes = 0;
+    // per-pass log of the last device-resident ICP loop on this context (pcr_icp_pass_log): tile launch us, drain launch us, queue items
+    double pass_log[3][PCR_ICP_MAX_LOG];
+    int pass_log_n = 0;
+    double loop_dev_ms = 0.0;   // that loop's duration by the kernels' own 100-MHz clock (0: not measured)
+    double pass_host_us[6] = {0, 0, 0, 0, 0, 0};   // host phases of that call: set-up, enqueue of the first chunk, waiting for the device, whole loop; [4] HIP events: call start .. behind the last kernel
     int cu_count = 256;
     char name[256] = {0};
     int64_t hbm_bytes = 0;
 };
+
+// Waiting for the device WITHOUT sleeping on an interrupt: hipStreamSynchronize / hipEventSynchronize hand the thread to the
+// runtime's blocking wait after a short spin, and on this pool's (virtualised) hosts the wake-up then comes 30-45 ms late every
+// few dozen calls -- 1 M-point registrations whose kernels took their usual 15 ms were timed at 45-60 ms (the per-pass device log
+// of pcr_icp_pass_log showed every kernel at its usual duration and no gap between them: DESIGN section 3.1.7).  Polling the
+// stream's signal (hipStreamQuery reads it, no system call) does not depend on the interrupt; after two seconds of polling the
+// blocking call takes over.
+#include <chrono>
+static inline hipError_t pcr_sync(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return hipStreamSynchronize(s);
+        __builtin_ia32_pause();
+    }
+}
+static inline hipError_t pcr_event_sync(hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int spins = 0;; ++spins) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return hipEventSynchronize(ev);
+        __builtin_ia32_pause();
+    }
+}
 
 #define PCR_HIP(ctx, expr)                                                            \
     do {                                                                              \
@@ -218,6 +253,12 @@ struct pcr_icp_loop_args {
 // whole ICP loop on the device (grid index); fills res like the host loop of pcr_icp
 // device -> pageable host memory through a pinned double buffer (large results: a pageable copy runs at ~4.5 GB/s)
 PCR_HIDDEN int pcr_d2h_staged(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+// small results (<= PCR_SMALL_D2H_BYTES) by a kernel writing into a pinned, device-mapped block: no copy engine (see pcr_core.hip).
+// pcr_d2h_small synchronises the stream; _enqueue only launches (mapped_host_dst must be device-mapped pinned memory of the context)
+constexpr size_t PCR_SMALL_D2H_BYTES = 16384;
+PCR_HIDDEN int pcr_d2h_small(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+PCR_HIDDEN int pcr_wait_flag(pcr_ctx* ctx, double* flag_us);
+PCR_HIDDEN int pcr_d2h_small_enqueue(pcr_ctx* ctx, void* mapped_host_dst, const void* dev_src, size_t bytes);
 PCR_HIDDEN int pcr_grid_icp_loop(pcr_ctx* ctx, const pcr_index* idx, pcr_cloud* qc, const pcr_icp_params* params, const double T0[16],
                                  pcr_icp_result* res);
 

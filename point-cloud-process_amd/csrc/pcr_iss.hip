@@ -186,8 +186,8 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
     if (lambdas_out && (rc = pcr_d2h_staged(ctx, lambdas_out, d_lam, sizeof(double) * 3 * (size_t)n))) return rc;
     if (counts_out && (rc = pcr_d2h_staged(ctx, counts_out, d_counts, sizeof(int) * (size_t)n))) return rc;
     unsigned int n_cand = 0;
-    if (want_kp) PCR_HIP(ctx, hipMemcpyAsync(&n_cand, d_cand_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (want_kp) { if ((rc = pcr_d2h_small(ctx, &n_cand, d_cand_count, sizeof(unsigned int)))) return rc; }
+    else PCR_HIP(ctx, pcr_sync(ctx->stream));
     pcr_dev_free(ctx, d_counts, sizeof(int) * n);
     rc = PCR_OK;
     std::vector<double> cand_l3(n_cand);
@@ -196,7 +196,7 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
         if ((rc = pcr_dev_alloc(ctx, sizeof(double) * n_cand, (void**)&d_l3)) == PCR_OK) {
             hipLaunchKernelGGL(iss_cand_l3_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, ctx->stream, (const double*)d_lam, (const int*)d_cand, n_cand, d_l3);
             hipError_t e = hipMemcpyAsync(cand_l3.data(), d_l3, sizeof(double) * n_cand, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = pcr_sync(ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("pcr_iss: ") + hipGetErrorString(e); rc = PCR_E_HIP; }
             pcr_dev_free(ctx, d_l3, sizeof(double) * n_cand);
         }
@@ -214,7 +214,7 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
         if (n_cand) {
             std::vector<int> ids(n_cand);
             hipError_t e = hipMemcpyAsync(ids.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = pcr_sync(ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("pcr_iss: ") + hipGetErrorString(e); rc = PCR_E_HIP; }
             for (unsigned int j = 0; j < n_cand; ++j) cand[j] = cand_t{ids[j], cand_l3[j]};
         }
@@ -247,7 +247,7 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
                 hipLaunchKernelGGL(iss_gather_kernel, dim3(1), dim3((unsigned)BATCH), 0, ctx->stream, (const pcr_pt*)d_rows, (const int*)d_ids, (int)batch, d_batch);
                 e = hipMemcpyAsync(recs.data(), d_batch, sizeof(pcr_pt) * batch, hipMemcpyDeviceToHost, ctx->stream);
             }
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = pcr_sync(ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("pcr_iss (suppression): ") + hipGetErrorString(e); rc = PCR_E_HIP; break; }
             bool done = false;
             for (size_t j = 0; j < batch && !done; ++j) {

@@ -641,8 +641,7 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
             hipLaunchKernelGGL(knn_block_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_b, d_cnt_b, todo,
                                (const unsigned int*)d_cnt_a, PCR_KNN_LV);
         unsigned int n_redo[3] = {0, 0, 0};
-        PCR_HIP(ctx, hipMemcpyAsync(n_redo, d_cnt_a, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        { const int rc_n = pcr_d2h_small(ctx, n_redo, d_cnt_a, 3 * sizeof(unsigned int)); if (rc_n) return rc_n; }   // (synchronises; no copy engine)
         static const bool dbg = getenv("PCR_KNN_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "pcr_knn: %lld queries, k = %d: %u left by the first scan, %u by the wave-per-query boxes, %u to the descent\n", (long long)q, k, n_redo[2], n_redo[0], n_redo[1]);
         if (n_redo[1])
@@ -655,7 +654,7 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
     PCR_HIP(ctx, hipGetLastError());
     if ((rc = pcr_d2h_staged(ctx, idx_out, d_idx, sizeof(int) * (size_t)q * k))) return rc;
     if ((rc = pcr_d2h_staged(ctx, dist_out, d_dist, sizeof(double) * (size_t)q * k))) return rc;
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_HIP(ctx, pcr_sync(ctx->stream));
     return PCR_OK;
 }
 
@@ -679,7 +678,7 @@ int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries, int6
                            d_counts.as<long long>(), (const long long*)nullptr, (int*)nullptr, (double*)nullptr);
         PCR_HIP(ctx, hipGetLastError());
         PCR_HIP(ctx, hipMemcpyAsync(counts_out, d_counts.p, sizeof(long long) * q, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCR_HIP(ctx, pcr_sync(ctx->stream));
         return PCR_OK;
     }
     const int64_t total = offsets[q];
@@ -710,13 +709,13 @@ int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries, int6
         if ((rc = d_tmp.alloc(tb > 0 ? tb : 16))) return rc;
         PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(d_tmp.p, tb1, i1, i2, x1, x2, (unsigned int)total, (unsigned int)q, offs, offs + 1, 0, 32, ctx->stream));
         PCR_HIP(ctx, rocprim::segmented_radix_sort_pairs(d_tmp.p, tb2, x2, x1, i2, i1, (unsigned int)total, (unsigned int)q, offs, offs + 1, 0, 64, ctx->stream));
-        if (rt_on) { hipStreamSynchronize(ctx->stream); rt[1] = rt_now(); }
+        if (rt_on) { pcr_sync(ctx->stream); rt[1] = rt_now(); }
         if ((rc = pcr_d2h_staged(ctx, idx_out, i1, sizeof(int) * (size_t)total))) return rc;
         if (rt_on) rt[2] = rt_now();
         if ((rc = pcr_d2h_staged(ctx, dist_out, x1, sizeof(double) * (size_t)total))) return rc;
         if (rt_on) { rt[3] = rt_now(); fprintf(stderr, "pcr_radius: kernels + sorts %.2f ms, indices out %.2f ms (%.1f MB), distances out %.2f ms (%.1f MB)\n", rt[1] - rt[0], rt[2] - rt[1], 4e-6 * total, rt[3] - rt[2], 8e-6 * total); }
     }
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_HIP(ctx, pcr_sync(ctx->stream));
     return PCR_OK;
 }
 
@@ -751,7 +750,7 @@ int pcr_dbscan(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int min_pts,
         hipLaunchKernelGGL(radius_kernel, dim3(grid), dim3(256), 0, ctx->stream, index->view, (const double*)d_q, (long long)n, radius, d_counts,
                            (const long long*)nullptr, (int*)nullptr, (double*)nullptr);
         hipMemcpyAsync(counts.data(), d_counts, sizeof(long long) * n, hipMemcpyDeviceToHost, ctx->stream);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
+        if (pcr_sync(ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
         for (int64_t i = 0; i < n; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + counts[(size_t)i];
         const long long total = offs[(size_t)n];
         if ((rc = pcr_dev_alloc(ctx, sizeof(int) * (total + 1), (void**)&d_idx))) break;
@@ -761,7 +760,7 @@ int pcr_dbscan(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int min_pts,
                            (long long*)nullptr, (const long long*)d_offs, d_idx, d_dist);
         nbr.resize((size_t)total + 1);
         hipMemcpyAsync(nbr.data(), d_idx, sizeof(int) * total, hipMemcpyDeviceToHost, ctx->stream);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
+        if (pcr_sync(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
         pcr_dev_free(ctx, d_idx, sizeof(int) * (total + 1));
         pcr_dev_free(ctx, d_dist, sizeof(double) * (total + 1));
         d_idx = nullptr; d_dist = nullptr;

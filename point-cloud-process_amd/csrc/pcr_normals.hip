@@ -191,7 +191,7 @@ int pcr_pca(pcr_ctx* ctx, const pcr_cloud* cloud, double eigvals_out[3], double 
         hipLaunchKernelGGL(pca_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const pcr_pt*)cloud->d, n, mean[0], mean[1], mean[2], pass, d_part);
         PCR_HIP(ctx, hipGetLastError());
         PCR_HIP(ctx, hipMemcpyAsync(h.data(), d_part, sizeof(double) * 8 * grid, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCR_HIP(ctx, pcr_sync(ctx->stream));
         if (pass == 0) {
             for (int b = 0; b < grid; ++b)
                 for (int k = 0; k < 3; ++k) mean[k] += h[8 * b + k];
@@ -254,8 +254,7 @@ int pcr_normals(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double* normals_out
     PCR_HIP(ctx, hipMemcpyAsync(normals_out, d_nrm, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
     if (eigvals_out) PCR_HIP(ctx, hipMemcpyAsync(eigvals_out, d_ev, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
     if (neighbours_out) PCR_HIP(ctx, hipMemcpyAsync(neighbours_out, d_nbr, sizeof(int) * (size_t)k * n, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipMemcpyAsync(&n_redo, d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rc_n = pcr_d2h_small(ctx, &n_redo, d_count, sizeof(unsigned int)); if (rc_n) return rc_n; }   // (synchronises)
     rc = PCR_OK;
     if (getenv("PCR_NORMALS_DEBUG")) fprintf(stderr, "pcr_normals: redo=%u\n", n_redo);
     if (n_redo > 0) {

@@ -504,7 +504,7 @@ int pcr_voxel_keys(pcr_ctx* ctx, const double* xyz, int64_t n, double leaf, doub
     if (rc == PCR_OK) rc = voxel_prepare(ctx, c, leaf, d_h, false, &w);
     if (rc == PCR_OK) {
         PCR_HIP(ctx, hipMemcpyAsync(h_out, d_h, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCR_HIP(ctx, pcr_sync(ctx->stream));
         if (D_out)
             for (int k = 0; k < 3; ++k) D_out[k] = w.D[k];
     }
@@ -540,8 +540,7 @@ static int voxel_filter_impl(pcr_ctx* ctx, const pcr_cloud* in, double leaf, int
         PCR_HIP(ctx, hipGetLastError());
     }
     unsigned int ng = 0;
-    PCR_HIP(ctx, hipMemcpyAsync(&ng, w.n_groups, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rc_n = pcr_d2h_small(ctx, &ng, w.n_groups, sizeof(unsigned int)); if (rc_n) return rc_n; }   // (synchronises)
     const int64_t rows = mode == 2 ? (int64_t)ng : (ng > 0 ? (int64_t)ng - 1 : 0);
     *n_out = rows;
     voxel_release(ctx, &w);
@@ -559,7 +558,7 @@ int pcr_voxel_filter(pcr_ctx* ctx, const double* xyz, int64_t n, double leaf, in
     if (rc == PCR_OK) rc = voxel_filter_impl(ctx, c, leaf, mode, seed, nullptr, d_out, n_out);
     if (rc == PCR_OK && *n_out > 0) {
         PCR_HIP(ctx, hipMemcpyAsync(out_xyz, d_out, sizeof(double) * 3 * (*n_out), hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCR_HIP(ctx, pcr_sync(ctx->stream));
     }
     if (d_out) pcr_dev_free(ctx, d_out, sizeof(double) * 3 * n);
     pcr_cloud_free(ctx, c);

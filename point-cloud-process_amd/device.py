@@ -59,11 +59,21 @@ class Context:
         L.check(L.lib().pcr_profile_read(self.handle, L.dptr(ms), C.byref(n)), self.handle)
         return ms, n.value
 
+    def pass_log(self):
+        """Per-pass log of the last device-resident ICP loop on this context: {"tile_us": [...], "drain_us": [...], "items": [...]}."""
+        t, d, it, n = np.zeros(L.PCR_ICP_MAX_LOG), np.zeros(L.PCR_ICP_MAX_LOG), np.zeros(L.PCR_ICP_MAX_LOG, dtype=np.int64), C.c_int()
+        h = np.zeros(6)
+        L.check(L.lib().pcr_icp_pass_log(self.handle, L.PCR_ICP_MAX_LOG, L.dptr(t), L.dptr(d), L.lptr(it), C.byref(n), L.dptr(h)), self.handle)
+        k = min(n.value, L.PCR_ICP_MAX_LOG)
+        return {"tile_us": t[:k].tolist(), "drain_us": d[:k].tolist(), "items": it[:k].tolist(),
+                "host_us": {"setup": h[0], "enqueue_first_chunk": h[1], "waiting_for_device": h[2], "whole_loop": h[3], "events_start_to_last_kernel": h[4], "last_wait": h[5]}}
+
     def search_stats(self):
-        """Diagnostics of the last correspondence search: {"brute_fallback": queries re-done by the exact sweep}."""
+        """Diagnostics: {"brute_fallback": queries the last brute-force search re-did by the exact sweep, "arena_allocations" /
+        "arena_allocation_us" / "arenas": device arenas this context has allocated so far, the host time that took, arenas held}."""
         out = np.zeros(4, dtype=np.int64)
         L.check(L.lib().pcr_search_stats(self.handle, L.lptr(out)), self.handle)
-        return {"brute_fallback": int(out[0])}
+        return {"brute_fallback": int(out[0]), "arena_allocations": int(out[1]), "arena_allocation_us": int(out[2]), "arenas": int(out[3])}
 
     def close(self):
         if self._h:

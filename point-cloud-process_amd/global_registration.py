@@ -17,7 +17,7 @@ from .device import DeviceCloud, TargetIndex, default_context, points_of
 from .registration import PointCloud, read_bin_velodyne
 
 __all__ = [
-    "Feature", "RegistrationResult", "voxel_down_sample", "estimate_normals_hybrid", "compute_fpfh_feature", "find_matchings",
+    "Feature", "RegistrationResult", "voxel_down_sample", "voxel_down_sample_device", "estimate_normals_hybrid", "compute_fpfh_feature", "find_matchings",
     "registration_ransac_based_on_feature_matching", "preprocess_point_cloud", "prepare_dataset", "execute_global_registration",
     "ransac_init",
 ]
@@ -164,6 +164,14 @@ def voxel_down_sample(points, voxel_size, ctx=None):
     L.check(L.lib().pcr_voxel_filter(ctx.handle, L.dptr(pc), pc.shape[0], float(voxel_size), 2, C.c_uint64(0), L.dptr(out), C.byref(n_out)),
             ctx.handle)
     return out[: n_out.value].copy()
+
+
+def voxel_down_sample_device(cloud, voxel_size, ctx=None):
+    """voxel_down_sample on a DeviceCloud -> DeviceCloud (rows ordered by voxel key); nothing leaves the device."""
+    ctx = ctx or cloud.ctx
+    h = C.c_void_p()
+    L.check(L.lib().pcr_voxel_filter_cloud(ctx.handle, cloud.handle, float(voxel_size), 2, C.c_uint64(0), C.byref(h)), ctx.handle)
+    return DeviceCloud(ctx, h, L.lib().pcr_cloud_size(h))
 
 
 def estimate_normals_hybrid(points, radius, max_nn=30, orient=True, viewpoint=(0.0, 0.0, 0.0), ctx=None):

@@ -26,4 +26,11 @@ for rep, IT in enumerate([int(x) for x in os.environ.get("SEQ", "20,20,20,20").s
     r = pkg.icp_device(sd, index, np.eye(4), mode="total", max_iter=IT, r_thres=-1.0, t_thres=-1.0, max_d2=5.0, min_iter=IT)
     ctx.sync(); w = time.perf_counter() - t0
     print(stage, "rep", rep, "iters", IT, "total device ms %.2f" % r["device_ms"], "device ms/iter %.3f wall %.3f" % (r["device_ms"] / r["iters"], 1e3 * w / r["iters"]), flush=True)
+    print("   ", ctx.search_stats())
+    lg = ctx.pass_log()
+    print("    host us", lg["host_us"], "sum of kernels us %.0f" % (sum(lg["tile_us"]) + sum(lg["drain_us"])))
+    if os.environ.get("PASSLOG", "1") != "0":
+        print("   tile us ", " ".join("%.0f" % v for v in lg["tile_us"]))
+        print("   drain us", " ".join("%.0f" % v for v in lg["drain_us"]))
+        print("   items   ", " ".join("%d" % v for v in lg["items"]), flush=True)
     sd.free()
