@@ -45,6 +45,7 @@ N_POINTS = 120_000
 MAX_D2 = 5.0
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix; scripts/mfma_f64_peak measures the achievable rate
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+PCIE_PEAK_GBS = 63.0           # PCIe 5.0 x16, one direction
 # algorithmic HBM bytes per correspondence of the grid pass: SURVEY 8d's figure (16 B query + 16 B matched target + 8 B result);
 # the binary64 record layout actually moves 100 B (32 B source record read + 32 B written back in place + 32 B matched target
 # record + 4 B result slot): reported beside it as `frac_f64_layout`
@@ -59,11 +60,11 @@ BATCH_PAIRS, BATCH_POINTS = 256, 20_000
 def profile_file(name):
     """Newest committed rocprofv3 counter summary of that name under profiles/ (r03_..., else r02_...): counters cannot be
     collected inside this process, so the per-launch HBM traffic and instruction counts come from the committed passes."""
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", f"{tag}_{name}")
         if os.path.exists(p):
             return p
-    return os.path.join(ROOT, "profiles", "r03_" + name)
+    return os.path.join(ROOT, "profiles", "r04_" + name)
 
 
 def launch_ranks(n):
@@ -285,6 +286,10 @@ def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
                     # both clouds of every pair as 16-B records over the wall time, against N x 8 TB/s
                     "hbm_frac_algorithmic": BATCH_PAIRS * 2 * BATCH_POINTS * 16 / el / (HBM_PEAK_GBS * 1e9 * world),
                     "pcie_bytes": (hi - lo) * 2 * BATCH_POINTS * 12,
+                    # what bounds the batch: both clouds of every pair cross PCIe once as packed float32 coordinates (12 B per point)
+                    "roofline_pcie": {"bound": "pcie", "achieved": (hi - lo) * 2 * BATCH_POINTS * 12 / el / 1e9, "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                                      "frac": (hi - lo) * 2 * BATCH_POINTS * 12 / el / 1e9 / PCIE_PEAK_GBS,
+                                      "note": "host -> device bytes of this rank over the whole batch's wall time, against the 63 GB/s of a PCIe 5.0 x16 link"},
                     "correspondences_per_s": float(iters.sum()) * BATCH_POINTS / el, "mean_iters": float(iters.mean()),
                     "results_gathered": len(res)}
         if errs:
@@ -295,7 +300,7 @@ def batch_leg(pkg, torch, dist, rank, world, dev_id, tdev, streams):
             # the per-pair path on the same contexts (what round 2 shipped), and bitwise agreement of the two
             os.environ["PCR_BATCH_PER_PAIR"] = "1"
             try:
-                el_pp, res_pp = timed(kw, 2)
+                el_pp, res_pp = timed(kw, 8)
             finally:
                 del os.environ["PCR_BATCH_PER_PAIR"]
             out[tag]["per_pair_path"] = {"seconds": el_pp, "pairs_per_s": BATCH_PAIRS / el_pp,
@@ -503,17 +508,31 @@ def config5_leg(pkg, ctx):
     # steady-state iteration at 1 M x 1 M, inputs resident
     index = pkg.TargetIndex(pkg.DeviceCloud.upload(world, ctx), ctx=ctx)
     run_icp_steps(pkg, index, src, 2, ctx)   # untimed: the context's arena grows to the 1 M-point scratch here (hipMalloc), not in the timed call
-    # best of three 20-iteration calls: single calls of this leg have come out 2-4 x slower on some boxes (0.78 -> 1.6-3.0 ms per
-    # iteration) without anything in this process explaining it; all three are kept in `icp_1m_calls_ms`
-    runs = [run_icp_steps(pkg, index, src, 20, ctx) for _ in range(3)]
-    r = min(runs, key=lambda x: x["device_ms"])
+    # Three 20-iteration calls from the 0.8 m / 3 degree offset; the MEDIAN is the headline and every call is listed with what the
+    # library's own per-pass log says about it (pcr_icp_pass_log: the kernels' 100-MHz clock): the tile and drain launches of every
+    # pass, the queries the tiles handed to the queue, and the call's phases on the host.  (Rounds 2-3 took the best of three because
+    # single calls came out 2-4 x slower now and then; with the log a slow call says where it was slow: DESIGN section 3.1.7.)
+    runs, calls = [], []
+    for _ in range(3):
+        x = run_icp_steps(pkg, index, src, 20, ctx)
+        lg = ctx.pass_log()
+        runs.append(x)
+        calls.append({"device_ms": x["device_ms"], "wall_ms": 1e3 * x["wall_s"], "kernels_ms_by_their_own_clock": 1e-3 * (sum(lg["tile_us"]) + sum(lg["drain_us"])),
+                      "tile_launch_us": {"first_pass": lg["tile_us"][0], "later_mean": float(np.mean(lg["tile_us"][1:]))},
+                      "drain_launch_us": {"first_pass": lg["drain_us"][0], "passes_2_to_10_mean": float(np.mean(lg["drain_us"][1:10])), "passes_11_to_20_mean": float(np.mean(lg["drain_us"][10:]))},
+                      "queue_items": {"first_pass": lg["items"][0], "pass_2": lg["items"][1], "pass_10": lg["items"][9], "pass_20": lg["items"][-1]},
+                      "per_pass_us": [round(a + b, 1) for a, b in zip(lg["tile_us"], lg["drain_us"])],
+                      "host_us": {k: round(float(v), 1) for k, v in lg["host_us"].items()}})
+    r = sorted(runs, key=lambda x: x["device_ms"])[1]
     index.free()
     algo = 52.0 * len(world)   # 52 B per point (two passes over the records + counts + eigenvalues out)
     return {"points": int(len(world)), "iss_radius_m": radius, "mean_neighbours": float(counts.mean()), "keypoints": len(kp),
             "iss_ms": 1e3 * iss_wall, "iss_ms_with_per_point_eigenvalues_and_counts": 1e3 * iss_wall_details, "iss_device_ms": iss_dev_ms,
             "coarse_to_fine_icp_s": c2f_wall, "coarse_to_fine_levels": [{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in lg.items()} for lg in logs],
             "T_error_vs_truth_max_abs": float(np.abs(T - T_off).max()),
+            "icp_1m_calls": calls,
             "icp_1m_calls_ms": [x["device_ms"] for x in runs],
+            "icp_1m_headline": "median of the three calls (device time by the kernels' own clock: first kernel of the call .. end of its last pass)",
             "icp_1m_ms_per_iter": r["device_ms"] / r["iters"], "icp_1m_correspondences_per_s": len(world) / (r["device_ms"] / r["iters"] * 1e-3),
             "roofline": {"bound": "hbm", "kernel": "pcr_iss (keypoints only), all launches incl. the grid build (HIP events on the library's stream)",
                          "achieved": algo / (iss_dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -729,7 +748,6 @@ def main():
             if a.nn == "grid" and a.points <= 200_000:
                 line["parity"] = parity_gates(pkg, index, src, tgt)
         print(json.dumps(line))
-    sd_timed.free()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

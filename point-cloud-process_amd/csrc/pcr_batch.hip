@@ -25,6 +25,9 @@
 #include <mutex>
 #include <chrono>
 #include <thread>
+#include <sched.h>
+#include <pthread.h>
+#include <cctype>
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "pcr_internal.h"
@@ -887,13 +890,66 @@ int batch_job::end() {
     return PCR_OK;
 }
 
+// CPUs of the NUMA node the device hangs off (sysfs: /sys/bus/pci/devices/<bdf>/numa_node, /sys/devices/system/node/node<N>/cpulist):
+// the packing threads of a rank read 245 MB of 24-byte records and write 123 MB of pinned staging memory per 256-pair batch, and with
+// eight ranks of a node doing that at once, memory on the far socket halves it.  false: unknown (no pinning).
+bool device_numa_cpus(int device, cpu_set_t* set) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (char* c = bdf; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    char path[256];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return false;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return false;
+    char list[4096] = {0};
+    const size_t nr = fread(list, 1, sizeof(list) - 1, f);
+    fclose(f);
+    if (nr == 0) return false;
+    CPU_ZERO(set);
+    int n_set = 0;
+    for (char* p = list; *p;) {   // "0-63,128-191"
+        char* end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, set); ++n_set; }
+        while (*p == ',' || *p == '\n' || *p == ' ') ++p;
+    }
+    // only inside what the process may use at all
+    cpu_set_t mine;
+    if (sched_getaffinity(0, sizeof(mine), &mine) == 0) {
+        int both = 0;
+        for (int c = 0; c < CPU_SETSIZE; ++c) {
+            if (CPU_ISSET(c, set) && !CPU_ISSET(c, &mine)) CPU_CLR(c, set);
+            if (CPU_ISSET(c, set)) ++both;
+        }
+        n_set = both;
+    }
+    return n_set > 0;
+}
+
 // threads of a batch call: created one by one, so that a refused thread (EAGAIN under a process limit) degrades the pool instead of
-// letting std::system_error escape through the C ABI; with none, the caller runs the work itself
+// letting std::system_error escape through the C ABI; with none, the caller runs the work itself.  `cpus` (may be null): the
+// spawned threads are bound to that set (the caller's own thread keeps its affinity).
 template <typename F>
-void run_pool(int n_workers, F&& worker) {
+void run_pool(int n_workers, F&& worker, const cpu_set_t* cpus = nullptr) {
     std::vector<std::thread> pool;
     for (int c = 1; c < n_workers; ++c) {
-        try { pool.emplace_back(worker); }
+        try {
+            pool.emplace_back([&worker, cpus] {
+                if (cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), cpus);
+                worker();
+            });
+        }
         catch (...) { break; }
     }
     worker();
@@ -927,6 +983,16 @@ int batch_run(pcr_ctx* const* ctxs, int n_ctx, batch_call& call, const pcr_icp_p
     }
     // (a smaller first sub-batch -- device work after a quarter of a packing time -- measured 5.4 against 4.8-5.1 ms: not adopted)
     std::vector<int64_t> bounds(1, 0);
+    // PCR_BATCH_SPLIT="a,b,c": sizes of the first sub-batches (then `sub` again): experiments with a short first / last one
+    if (const char* split_s = fused ? getenv("PCR_BATCH_SPLIT") : nullptr) {
+        for (const char* p = split_s; *p && bounds.back() < n_pairs;) {
+            char* end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            if (v > 0) bounds.push_back(bounds.back() + v < n_pairs ? bounds.back() + v : n_pairs);
+            p = *end ? end + 1 : end;
+        }
+    }
     while (bounds.back() < n_pairs) bounds.push_back(bounds.back() + sub < n_pairs ? bounds.back() + sub : n_pairs);
     const int64_t n_sub = (int64_t)bounds.size() - 1;
     std::vector<int32_t> status_own;
@@ -1035,12 +1101,17 @@ int batch_run(pcr_ctx* const* ctxs, int n_ctx, batch_call& call, const pcr_icp_p
         // Packing (6-float records -> packed coordinates in the mapped staging block: 0.75 ms per sub-batch of 64 pairs on eight
         // threads) is the critical path of a compat-mode batch -- every sub-batch's key kernel waits for it --, and the thread that
         // launches a sub-batch leaves the pool until that sub-batch is done.  Threads are not tied to contexts: more of them pack.
+        // Default: two threads per context, at most 16 (a rank's share of the host on an 8-GPU node; 256 pairs on 8 contexts, C call:
+        // 8 threads 5.5-5.8 ms, 12: 4.9-5.3, 16: 4.6-4.9, 24: no better), bound to the NUMA node of the device.
         const char* thr_s = getenv("PCR_BATCH_THREADS");
-        int n_workers = thr_s ? atoi(thr_s) : n_ctx;
+        int n_workers = thr_s ? atoi(thr_s) : (2 * n_ctx < 16 ? 2 * n_ctx : (n_ctx > 16 ? n_ctx : 16));
         if (n_workers < 1) n_workers = 1;
         if (n_workers > 64) n_workers = 64;
         if ((int64_t)n_workers > n_tasks) n_workers = (int)n_tasks;
-        run_pool(n_workers, worker);
+        cpu_set_t node_cpus;
+        static const bool no_pin = getenv("PCR_BATCH_NO_PIN") != nullptr;
+        const bool pin = !no_pin && device_numa_cpus(ctxs[0]->device, &node_cpus);
+        run_pool(n_workers, worker, pin ? &node_cpus : nullptr);
         // what later sub-batches read of earlier ones: back to the arenas now that every stream has been waited for
         for (auto& S : subs)
             if (S.job && S.job->own_event) hipEventDestroy(S.job->own_event);
