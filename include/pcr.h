@@ -108,6 +108,13 @@ PCR_API int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries_
 PCR_API int pcr_radius(pcr_ctx* ctx, const pcr_index* index, const double* queries_xyz, int64_t q, double radius,
                        int64_t* counts_out, const int64_t* offsets, int32_t* idx_out, double* dist_out);
 
+/* A handful of radius queries (q <= 64) in one call and one launch -- the reference's API is one query per call (kdtree.py:176-208,
+ * octree.py:166-259): counts_out[q] = neighbours of every query; idx_out / dist_out receive the lists back to back (query i at the
+ * sum of the counts before it), ascending distance, ties by index; they must hold q * cap entries.  A query with more than `cap`
+ * neighbours makes the call return PCR_E_UNSUPPORTED with counts_out filled: take the two-pass pcr_radius then.                  */
+PCR_API int pcr_radius_small(pcr_ctx* ctx, const pcr_index* index, const double* queries_xyz, int q, double radius, int64_t cap,
+                             int64_t* counts_out, int32_t* idx_out, double* dist_out);
+
 /* -------------------------------------------------------------------- ICP */
 enum { PCR_ICP_COMPAT_MAIN = 0, /* Registration/main.py:97-156 semantics, returns LAST increment */
        PCR_ICP_TOTAL = 1        /* icp_template.py:128-200 semantics, returns composed transform */ };

@@ -153,6 +153,7 @@ SIGNATURES = {
     "pcr_nn1": (C.c_int, [_vp, _vp, _vp, _dp, C.c_double, _ip, _dp]),
     "pcr_knn": (C.c_int, [_vp, _vp, _dp, C.c_int64, C.c_int, _ip, _dp]),
     "pcr_radius": (C.c_int, [_vp, _vp, _dp, C.c_int64, C.c_double, _lp, _lp, _ip, _dp]),
+    "pcr_radius_small": (C.c_int, [_vp, _vp, _dp, C.c_int, C.c_double, C.c_int64, _lp, _ip, _dp]),
     "pcr_icp_default_params": (None, [C.POINTER(IcpParams)]),
     "pcr_icp": (C.c_int, [_vp, _vp, _vp, C.POINTER(IcpParams), _dp, C.POINTER(IcpResult)]),
     "pcr_icp_batch": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(Pair), C.c_int64, C.POINTER(IcpParams), C.POINTER(IcpResult), _ip]),

@@ -98,6 +98,7 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     if (c->h_slabs) hipHostFree(c->h_slabs);
     if (c->h_state) hipHostFree(c->h_state);
     if (c->h_small) hipHostFree(c->h_small);
+    if (c->h_big) hipHostFree(c->h_big);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_down) hipHostFree(c->h_down);
     hipEventDestroy(c->ev0);

@@ -1213,7 +1213,14 @@ constexpr unsigned long long ITEM_NONE = ~0ull;           // "not written yet": 
 // clean it up (the whole queue is re-initialised per ICP call).
 constexpr unsigned int POISON_HI = 0xfffffffeu;
 __device__ static inline unsigned long long item_poison(unsigned int pass_id) { return ((unsigned long long)POISON_HI << 32) | pass_id; }
-constexpr unsigned int PASS_SPIN_LIMIT = 1u << 21;        // polls (>= 1 us each) before a wave gives up and flags an error (never seen)
+#ifndef PCR_PASS_SPIN_LIMIT
+#define PCR_PASS_SPIN_LIMIT (1u << 21)
+#endif
+// polls (>= 1 us each) before a waiting wave gives up.  Giving up is SAFE: the wave says so with its ticket, and the launch's last
+// wave then walks every reserved slot and serves what is still there (all tiles are done by then: every reserved item has been
+// written) -- same integers into the accumulators, same result bit for bit.  Never seen with the default; a build with
+// -DPCR_PASS_SPIN_LIMIT=2 makes almost every waiter give up (tests/test_gpu_queue_giveup.py).
+constexpr unsigned int PASS_SPIN_LIMIT = PCR_PASS_SPIN_LIMIT;
 constexpr int Q_BITS = 22;                                // reserved / claimed fields; done has the upper 20 bits
 constexpr unsigned long long Q_MASK = (1ull << Q_BITS) - 1ull;
 constexpr long long PASS_MAX_NQ = 1ll << 26;              // 32 groups x 2^22 slots, with room for the poison range
@@ -1637,13 +1644,19 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
         // Tickets carry a second count in their upper half: waves that left the queue by reading the poison.  Such a wave held an
         // index >= the final slot count of its group, so every slot below it had been claimed: a group with one of them has nothing
         // unclaimed, and when every group has one the last wave need not look at the queue words at all.
+        // (third field, bits 48+: waves that gave up waiting -- each holds a slot index whose item came, or will have come, after it left)
         if (lane == 0) {
-            if (failed) st_dev(root + 16, 1ull);
-            const unsigned long long tg_old = __hip_atomic_fetch_add(g_ticket, 1ull | (left_by_poison ? 1ull << 32 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long tg_old = __hip_atomic_fetch_add(g_ticket, 1ull | (left_by_poison ? 1ull << 32 : 0ull) | (failed ? 1ull << 48 : 0ull), __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned int)tg_old == g_tiles - 1u) {
-                const bool g_clean = (tg_old >> 32) != 0 || left_by_poison;
-                const unsigned long long tr_old = __hip_atomic_fetch_add(root, 1ull | (g_clean ? 1ull << 32 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned int)tr_old == n_groups - 1u) last = ((unsigned int)(tr_old >> 32) + (g_clean ? 1u : 0u) == n_groups) ? 1 : 2;   // 2: look for unclaimed items
+                const bool g_clean = ((tg_old >> 32) & 0xffffull) != 0 || left_by_poison;
+                const bool g_failed = (tg_old >> 48) != 0 || failed;
+                const unsigned long long tr_old = __hip_atomic_fetch_add(root, 1ull | (g_clean ? 1ull << 32 : 0ull) | (g_failed ? 1ull << 48 : 0ull), __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)tr_old == n_groups - 1u) {
+                    last = ((unsigned int)((tr_old >> 32) & 0xffffull) + (g_clean ? 1u : 0u) == n_groups) ? 1 : 2;   // 2: look for unclaimed items
+                    if ((tr_old >> 48) != 0 || g_failed) last = 3;                                                    // 3: somebody gave up: look at every reserved slot
+                }
             }
         }
     }
@@ -1656,10 +1669,13 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
     // ---- last wave of the launch.  Nobody is OBLIGED to wait for work (a wave that cannot see every tile of the launch started
     // leaves when it finds nothing), so items reserved after the last wave of their group left may still sit in the queue: unless
     // every group reported a wave that left by the poison, look for them and serve them here.  Then clean the queue words.
-    if (last == 2) {
+    if (last == 3 && dbg_arg && lane == 0) atomicAdd(&dbg_arg[(1 << 19) - 16], 1ull);   // (PCR_DEBUG_STAMPS: passes in which a waiter gave up)
+    if (last >= 2) {
         unsigned long long qw = 0;
         if (lane < (int)n_groups) qw = ld_dev(A.sync + (size_t)PASS_SYNC_STRIDE * lane);
-        const unsigned int r_l = (unsigned int)(qw & Q_MASK), c_l = (unsigned int)((qw >> Q_BITS) & Q_MASK);
+        const unsigned int r_l = (unsigned int)(qw & Q_MASK);
+        // (a wave gave up: its slot lies BELOW the claimed count -- every reserved slot is looked at; served ones read all-ones)
+        const unsigned int c_l = last == 3 ? 0u : (unsigned int)((qw >> Q_BITS) & Q_MASK);
         unsigned long long left = __ballot(lane < (int)n_groups && c_l < r_l);
         while (left) {
             const int gg = (int)__ffsll((long long)left) - 1;
@@ -1669,12 +1685,18 @@ grid_pass_kernel(const pcr_grid_view* __restrict__ gvp, pcr_grid_view gv, pcr_pt
                 unsigned long long* it = A.items + ((size_t)gg * A.cap + i) * 4;
                 unsigned long long w = ITEM_NONE;
                 bool arrived = false;
-                for (unsigned int spins = 0; spins < PASS_SPIN_LIMIT; ++spins) {
+                // (every tile of the launch is done -- its wave took its ticket behind its stores --, so an item that is not there by now
+                // was served: one look suffices when sweeping after a give-up; the unclaimed range keeps its patience)
+                const unsigned int patience = last == 3 ? 64u : (PASS_SPIN_LIMIT < (1u << 21) ? (1u << 21) : PASS_SPIN_LIMIT);
+                bool served_before = false;
+                for (unsigned int spins = 0; spins < patience; ++spins) {
                     if (lane < 4) w = ld_dev(it + lane);
                     const unsigned int w3_hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), 3);
                     if (__ballot(lane < 4 && w != ITEM_NONE && !(lane == 3 && w3_hi == POISON_HI)) == 0xfull) { arrived = true; break; }
+                    if (last == 3 && __ballot(lane < 4 && w == ITEM_NONE) == 0xfull) { served_before = true; break; }   // taken and cleaned by the wave that served it
                     __builtin_amdgcn_s_sleep(2);
                 }
+                if (served_before) continue;
                 if (lane < 4) st_dev(it + lane, ITEM_NONE);
                 // an item that never arrived (its words would decode to query 0xffffffff) is never served: the pass is flagged
                 // failed instead, pass_finish reports PCR_E_HIP for the call

@@ -105,6 +105,8 @@ struct pcr_ctx {
     double* h_pinned = nullptr;
     void* h_state = nullptr;              // pinned, device-mapped 8-KiB landing block of the device-resident ICP state (+ its pass log)
     void* h_small = nullptr;              // pinned, device-mapped landing block of pcr_d2h_small
+    void* h_big = nullptr;                // pinned, device-mapped landing block of the few-query k-NN / radius paths (grown on demand)
+    size_t h_big_bytes = 0;
     void* h_stage = nullptr;              // pinned staging buffer for uploads from pageable caller memory (grown on demand, <= 64 MiB)
     size_t h_stage_bytes = 0;
     void* h_down = nullptr;               // pinned double buffer for large device-to-host results (pcr_d2h_staged), 2 x h_down_half bytes

@@ -177,6 +177,7 @@ struct radius_scan {
     int* idx_out;              // null in the count pass
     double* dist_out;
     long long base;
+    unsigned int cap = 0xffffffffu;   // entries this query may write (single-call variant: what lies beyond is counted only)
     __device__ void operator()(unsigned int s, unsigned int e, double& bound2) {
         (void)bound2;
         for (unsigned int j0 = s; j0 < e; j0 += 64) {
@@ -193,8 +194,10 @@ struct radius_scan {
             const unsigned long long m = __ballot(hit);
             if (idx_out && hit) {
                 const unsigned int k = count + __popcll(m & ((1ull << lane) - 1ull));
-                idx_out[base + k] = (int)id;
-                dist_out[base + k] = d;
+                if (k < cap) {
+                    idx_out[base + k] = (int)id;
+                    dist_out[base + k] = d;
+                }
             }
             count += __popcll(m);
         }
@@ -587,15 +590,126 @@ knn_tile_kernel(pcr_grid_view gv, const double* __restrict__ queries, const unsi
     }
 }
 
+// A handful of queries in ONE launch (the reference's API is one query per call, kdtree.py:176-208, octree.py:166-259): every
+// query's neighbours go, unordered, straight into a pinned, device-mapped block of `cap` entries per query (what lies beyond is
+// only counted); the host orders them.  No count pass, no offsets, no device scratch, no copy.
+__global__ void __launch_bounds__(256)
+radius_small_kernel(pcr_grid_view gv, const double* __restrict__ queries, int nq, double radius, unsigned int cap, unsigned int* __restrict__ counts_out,
+                    int* __restrict__ idx_out, double* __restrict__ dist_out) {
+    __shared__ kn_entry s_stack[4][KN_STACK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = (int)blockIdx.x * 4 + wave;
+    if (qi >= nq) return;
+    radius_scan sc;
+    sc.pts = gv.pts;
+    sc.ax = queries[3 * qi];
+    sc.ay = queries[3 * qi + 1];
+    sc.az = queries[3 * qi + 2];
+    sc.radius = radius;
+    sc.lane = lane;
+    sc.count = 0;
+    sc.idx_out = idx_out;
+    sc.dist_out = dist_out;
+    sc.base = (long long)qi * cap;
+    sc.cap = cap;
+    double bound2 = radius * radius * (1.0 + 1e-12);
+    kn_descend(gv, sc.ax, sc.ay, sc.az, bound2, s_stack[wave], lane, sc);
+    if (lane == 0) counts_out[qi] = sc.count;
+}
+
+// pinned, device-mapped landing block for the few-query paths (grown on demand, kept with the context)
+static int small_block(pcr_ctx* ctx, size_t bytes, char** host, char** dev) {
+    if (ctx->h_big_bytes < bytes) {
+        if (ctx->h_big) hipHostFree(ctx->h_big);
+        ctx->h_big = nullptr;
+        ctx->h_big_bytes = 0;
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        if (hipHostMalloc(&ctx->h_big, want, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); ctx->h_big = nullptr; return PCR_E_NOMEM; }
+        ctx->h_big_bytes = want;
+    }
+    void* dp = nullptr;
+    PCR_HIP(ctx, hipHostGetDevicePointer(&dp, ctx->h_big, 0));
+    *host = (char*)ctx->h_big;
+    *dev = (char*)dp;
+    return PCR_OK;
+}
+
 extern "C" {
+
+int pcr_radius_small(pcr_ctx* ctx, const pcr_index* index, const double* queries, int q, double radius, int64_t cap, int64_t* counts_out,
+                     int32_t* idx_out, double* dist_out) {
+    if (!ctx || !index || !queries || !counts_out || !idx_out || !dist_out || !(radius >= 0) || q < 1 || q > 64 || cap < 1 || cap > (1 << 20)) return PCR_E_INVALID;
+    if (index->kind != PCR_INDEX_GRID) return PCR_E_UNSUPPORTED;
+    hipSetDevice(ctx->device);
+    // landing block: queries | counts | indices | distances
+    const size_t o_cnt = 24 * (size_t)q, o_idx = (o_cnt + 4 * (size_t)q + 63) & ~(size_t)63, o_d = (o_idx + 4 * (size_t)q * cap + 63) & ~(size_t)63;
+    const size_t bytes = o_d + 8 * (size_t)q * cap;
+    char *h = nullptr, *d = nullptr;
+    int rc = small_block(ctx, bytes, &h, &d);
+    if (rc) return rc;
+    memcpy(h, queries, 24 * (size_t)q);
+    hipLaunchKernelGGL(radius_small_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, ctx->stream, index->view, (const double*)d, q, radius, (unsigned int)cap,
+                       (unsigned int*)(d + o_cnt), (int*)(d + o_idx), (double*)(d + o_d));
+    PCR_HIP(ctx, hipGetLastError());
+    if ((rc = pcr_wait_flag(ctx, nullptr))) return rc;
+    const unsigned int* cnt = (const unsigned int*)(h + o_cnt);
+    bool over = false;
+    for (int i = 0; i < q; ++i) { counts_out[i] = cnt[i]; over = over || cnt[i] > (unsigned int)cap; }
+    if (over) return PCR_E_UNSUPPORTED;   // counts_out holds the true counts: the two-pass pcr_radius takes such queries
+    // ascending distance, ties by index (result_set.py:78-84 keeps insertion order; the reference's lists are sorted by the caller)
+    std::vector<std::pair<double, int>> tmp;
+    int64_t out = 0;
+    for (int i = 0; i < q; ++i) {
+        const int* ii = (const int*)(h + o_idx) + (size_t)i * cap;
+        const double* dd = (const double*)(h + o_d) + (size_t)i * cap;
+        tmp.resize(cnt[i]);
+        for (unsigned int k = 0; k < cnt[i]; ++k) tmp[k] = std::make_pair(dd[k], ii[k]);
+        std::sort(tmp.begin(), tmp.end());
+        for (unsigned int k = 0; k < cnt[i]; ++k) { dist_out[out + k] = tmp[k].first; idx_out[out + k] = tmp[k].second; }
+        out += cnt[i];
+    }
+    return PCR_OK;
+}
 
 int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t q, int k, int32_t* idx_out, double* dist_out) {
     if (!ctx || !index || !queries || !idx_out || !dist_out || k <= 0) return PCR_E_INVALID;
     if (q <= 0) return PCR_OK;
     if (index->kind != PCR_INDEX_GRID) return PCR_E_UNSUPPORTED;
     hipSetDevice(ctx->device);
-    pcr_dev_block b_q(ctx), b_idx(ctx), b_dist(ctx), b_redo(ctx);   // (back to the arena on every return path)
     int rc;
+    static const bool no_small = getenv("PCR_KNN_NO_SMALL") != nullptr;
+    if (q <= 16 && k <= 16 && !no_small) {
+        // A handful of queries (the reference's API is one per call, kdtree.py:141-172, octree.py:262-306): one query per wave with all
+        // 64 lanes on the query's own box (knn_tile_kernel, the second stage of the batched path), queries read from and results
+        // written to a pinned, device-mapped block -- one launch, no copies, no device scratch; what it cannot prove (clamped
+        // coordinates, fewer than k points) goes through the descent kernel, as in the batched path.
+        const size_t o_ord = 24 * (size_t)q, o_cnt = o_ord + 4 * (size_t)q, o_redo = o_cnt + 64, o_idx = (o_redo + 4 * (size_t)q + 63) & ~(size_t)63;
+        const size_t o_d = (o_idx + 4 * (size_t)q * k + 63) & ~(size_t)63, bytes = o_d + 8 * (size_t)q * k;
+        char *h = nullptr, *d = nullptr;
+        if ((rc = small_block(ctx, bytes, &h, &d))) return rc;
+        memcpy(h, queries, 24 * (size_t)q);
+        for (int64_t i = 0; i < q; ++i) ((unsigned int*)(h + o_ord))[i] = (unsigned int)i;
+        *(unsigned int*)(h + o_cnt) = 0u;
+        const unsigned gw = (unsigned)((q + 3) / 4);
+        if (k <= 8)
+            hipLaunchKernelGGL((knn_tile_kernel<8, 64, 7, 512>), dim3(gw), dim3(256), 0, ctx->stream, index->view, (const double*)d, (const unsigned int*)(d + o_ord), (long long)q,
+                               (const unsigned int*)nullptr, k, (int*)(d + o_idx), (double*)(d + o_d), (int*)(d + o_redo), (unsigned int*)(d + o_cnt));
+        else
+            hipLaunchKernelGGL((knn_tile_kernel<16, 64, 7, 512>), dim3(gw), dim3(256), 0, ctx->stream, index->view, (const double*)d, (const unsigned int*)(d + o_ord), (long long)q,
+                               (const unsigned int*)nullptr, k, (int*)(d + o_idx), (double*)(d + o_d), (int*)(d + o_redo), (unsigned int*)(d + o_cnt));
+        PCR_HIP(ctx, hipGetLastError());
+        if ((rc = pcr_wait_flag(ctx, nullptr))) return rc;
+        if (*(volatile unsigned int*)(h + o_cnt) != 0u) {
+            hipLaunchKernelGGL(knn_kernel, dim3(gw), dim3(256), 0, ctx->stream, index->view, (const double*)d, (long long)q, k, (int*)(d + o_idx), (double*)(d + o_d),
+                               (const int*)(d + o_redo), (const unsigned int*)(d + o_cnt));
+            PCR_HIP(ctx, hipGetLastError());
+            if ((rc = pcr_wait_flag(ctx, nullptr))) return rc;
+        }
+        memcpy(idx_out, h + o_idx, 4 * (size_t)q * k);
+        memcpy(dist_out, h + o_d, 8 * (size_t)q * k);
+        return PCR_OK;
+    }
+    pcr_dev_block b_q(ctx), b_idx(ctx), b_dist(ctx), b_redo(ctx);   // (back to the arena on every return path)
     if ((rc = b_q.alloc(sizeof(double) * 3 * q)) || (rc = b_idx.alloc(sizeof(int) * q * k)) || (rc = b_dist.alloc(sizeof(double) * q * k))) return rc;
     const double* d_q = b_q.as<const double>();
     int* d_idx = b_idx.as<int>();

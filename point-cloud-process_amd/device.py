@@ -227,6 +227,18 @@ class TargetIndex:
         q = L.as_f64(np.atleast_2d(queries))[:, :3].copy()
         nq = q.shape[0]
         counts = np.zeros(nq, dtype=np.int64)
+        if 1 <= nq <= 8:   # the reference's one-query-per-call API: one launch, results straight into pinned memory
+            cap = 8192
+            idx = np.empty(nq * cap, dtype=np.int32)
+            dist = np.empty(nq * cap, dtype=np.float64)
+            st = L.lib().pcr_radius_small(self.ctx.handle, self.handle, L.dptr(q), nq, float(r), cap, L.lptr(counts), L.iptr(idx), L.dptr(dist))
+            if st == L.PCR_OK:
+                offsets = np.zeros(nq + 1, dtype=np.int64)
+                np.cumsum(counts, out=offsets[1:])
+                m = int(offsets[-1])
+                return offsets, idx[:m], dist[:m]
+            if st != L.PCR_E_UNSUPPORTED:
+                L.check(st, self.ctx.handle)
         L.check(L.lib().pcr_radius(self.ctx.handle, self.handle, L.dptr(q), nq, float(r), L.lptr(counts), None, None, None), self.ctx.handle)
         offsets = np.zeros(nq + 1, dtype=np.int64)
         np.cumsum(counts, out=offsets[1:])

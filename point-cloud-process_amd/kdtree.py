@@ -58,8 +58,7 @@ def kdtree_radius_search(root, db, result_set: RadiusNNResultSet, query):
     if root is None:
         return False
     off, idx, dist = _index_of(root).radius(np.asarray(query, dtype=np.float64).reshape(1, 3), result_set.radius)
-    for d, i in zip(dist, idx):
-        result_set.add_point(d, int(i))
+    result_set.add_points(dist, idx) if hasattr(result_set, "add_points") else [result_set.add_point(d, int(i)) for d, i in zip(dist, idx)]
     return False
 
 

@@ -56,8 +56,7 @@ def octree_radius_search(root, db, result_set: RadiusNNResultSet, query):
     if root is None:
         return False
     off, idx, dist = root.index.radius(np.asarray(query, dtype=np.float64).reshape(1, 3), result_set.radius)
-    for d, i in zip(dist, idx):
-        result_set.add_point(d, int(i))
+    result_set.add_points(dist, idx) if hasattr(result_set, "add_points") else [result_set.add_point(d, int(i)) for d, i in zip(dist, idx)]
     return _inside(query, result_set.worstDist(), root)
 
 

@@ -48,9 +48,25 @@ class _Collector:
 
 
 class RadiusNNResultSet(_Collector):
+    """result_set.py:63-93.  ``add_points(dists, indices)`` takes a whole query result at once (what the device search returns):
+    the DistIndex objects of ``dist_index_list`` are then only made when the list is first looked at -- a radius-1 query on a
+    KITTI scan returns ~1 500 neighbours, and one Python object per neighbour cost ten times the search itself."""
+
     def __init__(self, radius):
         super().__init__()
-        self.radius = self.worst_dist = radius
+        self.radius = self.worst_dist = radius   # (the base class has set dist_index_list through the property below: _items, _pending)
+
+    @property
+    def dist_index_list(self):
+        if self._pending:
+            for d, i in self._pending:
+                self._items.extend(map(DistIndex, d.tolist(), i.tolist()))
+            self._pending = []
+        return self._items
+
+    @dist_index_list.setter
+    def dist_index_list(self, v):
+        self._items, self._pending = v, []
 
     def worstDist(self):
         return self.radius
@@ -61,11 +77,24 @@ class RadiusNNResultSet(_Collector):
             self.count += 1
             self.dist_index_list.append(DistIndex(dist, index))
 
+    def add_points(self, dists, indices):
+        """add_point for every (dist, index) pair of two equally long arrays, in order."""
+        import numpy as np
+
+        d = np.asarray(dists, dtype=np.float64).reshape(-1)
+        i = np.asarray(indices).reshape(-1)
+        self.comparison_counter += len(d)
+        keep = ~(d > self.radius)
+        if not keep.all():
+            d, i = d[keep], i[keep]
+        self.count += len(d)
+        if len(d):
+            self._pending.append((d, i))
+
     def __str__(self):
         self.dist_index_list.sort()
         return self._report("In total %d neighbors within %f.\nThere are %d comparison operations."
                             % (self.count, self.radius, self.comparison_counter))
-
 
 class KNNResultSet(_Collector):
     def __init__(self, capacity):
