@@ -264,7 +264,17 @@ int pcr_d2h_staged(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t byt
         }
     };
     std::thread th[W];
-    for (int w = 0; w < W; ++w) th[w] = std::thread(worker, w);
+    int started = 0;
+    try {
+        for (int w = 0; w < W; ++w) { th[w] = std::thread(worker, w); ++started; }
+    } catch (...) {
+        // a refused thread (EAGAIN under a process limit) must not escape through the C ABI: stop the ones that run, plain copy instead
+        failed.store(1, std::memory_order_relaxed);
+        for (int w = 0; w < started; ++w) th[w].join();
+        PCR_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, pcr_sync(ctx->stream));
+        return PCR_OK;
+    }
     hipError_t e = hipMemcpyAsync(pin, dev_src, chunk_bytes(0), hipMemcpyDeviceToHost, ctx->stream);
     for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
         e = pcr_sync(ctx->stream);   // chunk c is in its half

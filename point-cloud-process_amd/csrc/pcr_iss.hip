@@ -16,8 +16,11 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
+#include <string>
 #include <vector>
+#include <rocprim/rocprim.hpp>
 #include "pcr_grid_dev.h"
 
 constexpr int IG = 8;  // lanes per point
@@ -65,6 +68,17 @@ __global__ void __launch_bounds__(256) iss_count_kernel(pcr_grid_view gv, long l
     if (gl == 0) counts[p.id] = c;
 }
 
+// a point that passed the ratio tests: lambda_3, caller row, position in the index's sorted order (its coordinates are gv.pts[pos])
+struct __attribute__((aligned(16))) iss_cand {
+    double l3;
+    int id;
+    unsigned int pos;
+};
+// ISS.py:59-61 visits the candidates by descending lambda_3, ties in input order
+struct iss_cand_before {
+    __host__ __device__ bool operator()(const iss_cand& a, const iss_cand& b) const { return a.l3 > b.l3 || (a.l3 == b.l3 && a.id < b.id); }
+};
+
 // eigenvalues of a symmetric 3x3 matrix (cyclic Jacobi), descending
 __device__ static inline void sym3_eigenvalues(double a00, double a01, double a02, double a11, double a12, double a22, double ev[3]) {
     double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
@@ -99,7 +113,7 @@ __device__ static inline void sym3_eigenvalues(double a00, double a01, double a0
 __global__ void __launch_bounds__(256) iss_cov_kernel(pcr_grid_view gv, long long n, double r2_in, const int* __restrict__ counts,
                                                       double* __restrict__ lambdas /* by row id, (n,3) */, double gamma21, double gamma32,
                                                       int* __restrict__ cand /* row ids passing the ratio tests, any order */,
-                                                      unsigned int* __restrict__ cand_count) {
+                                                      unsigned int* __restrict__ cand_count, struct iss_cand* __restrict__ cand_rec /* or the records */) {
     const int gl = threadIdx.x % IG;
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / IG;
     if (i >= n) return;
@@ -131,10 +145,67 @@ __global__ void __launch_bounds__(256) iss_cov_kernel(pcr_grid_view gv, long lon
         lambdas[3 * p.id + 2] = ev[2];
         // ISS.py:55-57: candidate when both eigenvalue ratios pass (NaN ratios of degenerate neighbourhoods fail, like the
         // reference's comparisons do); the host orders the (unordered) list, so the append order does not matter
-        if (cand && ev[1] / ev[0] < gamma21 && ev[2] / ev[1] < gamma32) cand[atomicAdd(cand_count, 1u)] = (int)p.id;
+        if ((cand || cand_rec) && ev[1] / ev[0] < gamma21 && ev[2] / ev[1] < gamma32) {
+            const unsigned int slot = atomicAdd(cand_count, 1u);
+            if (cand_rec) cand_rec[slot] = iss_cand{ev[2], (int)p.id, (unsigned int)i};
+            else cand[slot] = (int)p.id;
+        }
     }
 }
 
+
+// Non-maximum suppression (ISS.py:59-73) on the device, ONE block: the candidates come sorted (descending lambda_3, ties by row);
+// the reference keeps a candidate unless an already kept keypoint lies within nms_radius, and stops once MORE than max_keypoints
+// were taken.  256 candidates per round: every thread tests its candidate against the keypoints kept so far (LDS); then, in
+// order, the first one still alive is kept and the rest of the round is tested against it, until nobody is left alive.
+constexpr int ISS_NMS_MAX = 1024;   // keypoints the block can hold in LDS (more: the host loop below)
+__global__ void __launch_bounds__(256)
+iss_nms_kernel(const pcr_pt* __restrict__ pts, const iss_cand* __restrict__ cand, unsigned int n_cand, double nms_radius, int max_keypoints,
+               int* __restrict__ keypoints_out /* mapped host memory */, int* __restrict__ n_out) {
+    __shared__ double kx[ISS_NMS_MAX + 1], ky[ISS_NMS_MAX + 1], kz[ISS_NMS_MAX + 1];
+    __shared__ int s_first, s_taken;
+    if (threadIdx.x == 0) s_taken = 0;
+    __syncthreads();
+    for (unsigned int base = 0; base < n_cand; base += 256) {
+        const unsigned int j = base + threadIdx.x;
+        bool alive = j < n_cand;
+        double x = 0, y = 0, z = 0;
+        int id = 0;
+        if (alive) {
+            const iss_cand c = cand[j];
+            const pcr_pt p = pts[c.pos];
+            x = p.x; y = p.y; z = p.z; id = c.id;
+        }
+        int checked = 0;   // keypoints this thread has tested its candidate against
+        for (;;) {
+            const int taken = s_taken;
+            for (; alive && checked < taken; ++checked) {
+                const double dx = kx[checked] - x, dy = ky[checked] - y, dz = kz[checked] - z;
+                const double d = sqrt((dx * dx + dy * dy) + dz * dz);   // the expression of the radius query (pcr_knn.hip)
+                if (!(d > nms_radius)) alive = false;
+            }
+            checked = taken;
+            __syncthreads();
+            if (threadIdx.x == 0) s_first = 0x7fffffff;
+            __syncthreads();
+            if (alive) atomicMin(&s_first, (int)threadIdx.x);
+            __syncthreads();
+            const int first = s_first;
+            if (first == 0x7fffffff) break;          // nobody of this round is left: next round
+            if ((int)threadIdx.x == first) {
+                kx[taken] = x; ky[taken] = y; kz[taken] = z;
+                keypoints_out[taken] = id;
+                s_taken = taken + 1;
+                alive = false;
+            }
+            __syncthreads();
+            if (s_taken > max_keypoints) break;      // ISS.py:72-73: stops once MORE than iss_count were taken
+        }
+        __syncthreads();
+        if (s_taken > max_keypoints) break;
+    }
+    if (threadIdx.x == 0) *n_out = s_taken;
+}
 
 __global__ void iss_cand_l3_kernel(const double* __restrict__ lam, const int* __restrict__ cand, unsigned int m, double* __restrict__ out) {
     const unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,17 +228,23 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
     int rc = pcr_index_build(ctx, cloud, PCR_INDEX_GRID, radius * (1.0 + 1e-9), &idx);  // block of 27 cells covers the ball with rounding slack
     if (rc) return rc;
     // the index may have coarsened the cell (huge extents): the 3x3x3 block then still covers the radius
-    if (idx->cell < radius * (1.0 - 1e-12)) { pcr_index_free(ctx, idx); return PCR_E_UNSUPPORTED; }
-    int* d_counts = nullptr;
-    double* d_lam = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(int) * n, (void**)&d_counts))) return rc;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 3 * n, (void**)&d_lam))) return rc;
+    if (idx->cell < radius * (1.0 - 1e-12)) { pcr_index_free(ctx, idx); idx = nullptr; return PCR_E_UNSUPPORTED; }
+    // (every scratch block and the index go back on every return path: ADVICE r3)
+    struct index_guard { pcr_ctx* c; pcr_index*& i; ~index_guard() { if (i) { pcr_index_free(c, i); i = nullptr; } } } idx_guard{ctx, idx};
+    pcr_dev_block b_counts(ctx), b_lam(ctx);
+    if ((rc = b_counts.alloc(sizeof(int) * n)) || (rc = b_lam.alloc(sizeof(double) * 3 * n))) return rc;
+    int* const d_counts = b_counts.as<int>();
+    double* const d_lam = b_lam.as<double>();
     const unsigned grid = (unsigned)((n * IG + 255) / 256);
     const bool want_kp = keypoints_out && n_keypoints_out;
+    static const bool host_nms = getenv("PCR_ISS_HOST_NMS") != nullptr;   // A/B: the host loop over a heap of the candidates
+    const bool dev_nms = want_kp && !host_nms && max_keypoints >= 0 && max_keypoints < ISS_NMS_MAX;
     int* d_cand = nullptr;
+    pcr_dev_block b_rec(ctx), b_rec2(ctx), b_tmp(ctx);
     unsigned int* d_cand_count = ctx->d_counters + 124;
     if (want_kp) {
-        if ((rc = pcr_dev_alloc(ctx, sizeof(int) * n, (void**)&d_cand))) return rc;
+        if (dev_nms) { if ((rc = b_rec.alloc(sizeof(iss_cand) * n))) return rc; }
+        else if ((rc = pcr_dev_alloc(ctx, sizeof(int) * n, (void**)&d_cand))) return rc;
         PCR_HIP(ctx, hipMemsetAsync(d_cand_count, 0, sizeof(unsigned int), ctx->stream));
     }
     // "within radius" is `not (sqrt(d2) > radius)` (the radius query's expression, pcr_knn.hip).  sqrt is monotone and correctly
@@ -178,7 +255,7 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
     while (sqrt(nextafter(r2_in, INFINITY)) <= radius) r2_in = nextafter(r2_in, INFINITY);
     hipLaunchKernelGGL(iss_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, r2_in, d_counts);
     hipLaunchKernelGGL(iss_cov_kernel, dim3(grid), dim3(256), 0, ctx->stream, idx->view, (long long)n, r2_in, (const int*)d_counts, d_lam, gamma21,
-                       gamma32, d_cand, d_cand_count);
+                       gamma32, d_cand, d_cand_count, b_rec.as<iss_cand>());
     PCR_HIP(ctx, hipGetLastError());
     // (24 MB + 4 MB at 1 M points: through the pinned double buffer, a pageable copy runs at ~4.5 GB/s.  Both are optional: a
     // caller that only wants the keypoints gets the candidates' lambda_3 in a compact list instead -- the copy was most of the
@@ -188,8 +265,38 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
     unsigned int n_cand = 0;
     if (want_kp) { if ((rc = pcr_d2h_small(ctx, &n_cand, d_cand_count, sizeof(unsigned int)))) return rc; }
     else PCR_HIP(ctx, pcr_sync(ctx->stream));
-    pcr_dev_free(ctx, d_counts, sizeof(int) * n);
+    b_counts.free_now();
     rc = PCR_OK;
+    if (dev_nms) {
+        // candidates ordered on the device (one merge sort with the reference's order as the comparison), suppression by one block,
+        // the <= max_keypoints + 1 row ids written straight into pinned memory: nothing but the count and the keypoints crosses PCIe
+        b_lam.free_now();
+        int taken = 0;
+        if (n_cand) {
+            size_t tb = 0;
+            iss_cand* recs = b_rec.as<iss_cand>();
+            hipError_t e = rocprim::merge_sort(nullptr, tb, recs, recs, (size_t)n_cand, iss_cand_before(), ctx->stream);
+            if (e == hipSuccess && (rc = b_tmp.alloc(tb > 0 ? tb : 16)) == PCR_OK) e = rocprim::merge_sort(b_tmp.p, tb, recs, recs, (size_t)n_cand, iss_cand_before(), ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("pcr_iss (candidate sort): ") + hipGetErrorString(e); rc = PCR_E_HIP; }
+            if (rc == PCR_OK) {
+                // landing block: [n_out][keypoints...] in the context's mapped small block
+                int* h_out = (int*)ctx->h_small;
+                int* d_out = nullptr;
+                if ((size_t)(max_keypoints + 2) * sizeof(int) > PCR_SMALL_D2H_BYTES || hipHostGetDevicePointer((void**)&d_out, h_out, 0) != hipSuccess) rc = PCR_E_HIP;
+                if (rc == PCR_OK) {
+                    hipLaunchKernelGGL(iss_nms_kernel, dim3(1), dim3(256), 0, ctx->stream, idx->view.pts, (const iss_cand*)recs, n_cand, nms_radius, max_keypoints, d_out + 1, d_out);
+                    if (hipGetLastError() != hipSuccess) rc = PCR_E_HIP;
+                    if (rc == PCR_OK) rc = pcr_wait_flag(ctx, nullptr);
+                    if (rc == PCR_OK) {
+                        taken = h_out[0];
+                        for (int k = 0; k < taken; ++k) keypoints_out[k] = h_out[1 + k];
+                    }
+                }
+            }
+        }
+        *n_keypoints_out = taken;
+        return rc;
+    }
     std::vector<double> cand_l3(n_cand);
     if (want_kp && n_cand) {   // lambda_3 of the candidates, in list order
         double* d_l3 = nullptr;
@@ -201,8 +308,8 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
             pcr_dev_free(ctx, d_l3, sizeof(double) * n_cand);
         }
     }
-    pcr_dev_free(ctx, d_lam, sizeof(double) * 3 * n);
-    if (rc) { if (d_cand) pcr_dev_free(ctx, d_cand, sizeof(int) * n); pcr_index_free(ctx, idx); return rc; }
+    b_lam.free_now();
+    if (rc) { if (d_cand) pcr_dev_free(ctx, d_cand, sizeof(int) * n); return rc; }
     if (want_kp) {
         // Non-maximum suppression (ISS.py:59-73).  The reference walks the candidates in descending lambda_3 (stable: ties
         // in input order) and, for each one still alive, keeps it and removes everything within nms_radius of it.  A
@@ -271,6 +378,5 @@ extern "C" int pcr_iss(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, doub
         pcr_dev_free(ctx, d_cand, sizeof(int) * n);
         *n_keypoints_out = taken;
     }
-    pcr_index_free(ctx, idx);
     return rc;
 }
