@@ -8,9 +8,10 @@ Pinned against the reference itself: tests/test_oracle_golden.py checks every
 function below against tests/golden/*.npz, which oracle/ref_harness.py produced
 by running the reference's own functions (Registration/main.py:icp_point2point,
 Pca_and_Voxel_filter/voxel_filter.py:voxel_filter, Kdtree_Octree/lesson2/*).
-Exception -- ISS: Keypoint_detection_ISS/ISS.py is a script body with no
-importable function and its input file is absent: ``iss_oracle`` restates
-ISS.py:41-73 line by line and is "parity unpinned".
+ISS (Keypoint_detection_ISS/ISS.py is a script body without importable
+functions): ``iss_oracle`` restates ISS.py:41-73 line by line and is pinned too
+-- tests/golden/iss.npz is what the script itself computes, run unmodified
+through runpy on seeded input files (oracle/ref_harness.py:gen_iss).
 
 Every function cites the reference lines it follows (paths relative to
 /root/reference).
