@@ -243,11 +243,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8
 knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long nq, int k, int* __restrict__ idx_out,
                  double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count,
                  const int* __restrict__ todo /* query ids to do (what the wave tiles left), or null: all */, const unsigned int* __restrict__ todo_count,
-                 int lv_cap /* highest level this launch may climb to */) {
+                 int lv_cap /* highest level this launch may climb to */,
+                 double* __restrict__ redo_kth /* (or null) next to every redo id: the squared k-th distance this scan found, DBL_MAX = fewer than k points */) {
     const long long ti = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long n_do = (todo && todo_count) ? (long long)*todo_count : nq;   // (a list without a count: all nq entries, e.g. the curve order)
     const long long qi = ti < n_do ? (todo ? (long long)todo[ti] : ti) : nq;
     bool proven = false;
+    double kth_seen = DBL_MAX;
     double bd[K];
     long long bi[K];
     if (qi < nq) {
@@ -320,6 +322,7 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
 #pragma unroll
             for (int j = 0; j < K; ++j) kth = (j == k - 1) ? bd[j] : kth;
             proven = kth <= cover * cover;
+            kth_seen = kth;   // k points this close exist: the ball that holds the answer
         }
         if (proven) {
 #pragma unroll
@@ -338,7 +341,11 @@ knn_block_kernel(pcr_grid_view gv, const double* __restrict__ queries, long long
         unsigned int base = 0;
         if (lane == 0) base = atomicAdd(redo_count, (unsigned int)__popcll(m));
         base = __shfl(base, 0, 64);
-        if (redo) redo_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)qi;
+        if (redo) {
+            const unsigned int at = base + __popcll(m & ((1ull << lane) - 1ull));
+            redo_list[at] = (int)qi;
+            if (redo_kth) redo_kth[at] = kth_seen;
+        }
     }
 }
 
@@ -386,7 +393,8 @@ __device__ static inline int kt_wave_max(int v) {
 template <int K, int LPQ, int PASSES, int ROUNDS>
 __device__ static void knn_tile_one(const pcr_grid_view& gv, knn_tile_lds* L, const int lane, const long long tile, const long long nq,
                                     const double* __restrict__ queries, const unsigned int* __restrict__ order, int k, int* __restrict__ idx_out,
-                                    double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count) {
+                                    double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count,
+                                    const double* __restrict__ seed_kth) {
     constexpr int QPT = 64 / LPQ;
     const int sub = lane & (LPQ - 1);
     const long long slot = tile * QPT + (lane / LPQ);
@@ -408,13 +416,19 @@ __device__ static void knn_tile_one(const pcr_grid_view& gv, knn_tile_lds* L, co
 #pragma unroll
     for (int j = 0; j < K; ++j) { bd[j] = DBL_MAX; bi[j] = 0x7fffffffffffffffll; }
     const int top = gv.levels - 1;
-    for (int pass = 0; pass < PASSES; ++pass) {
+    // `seed_kth` (the first stage's lists): that scan has been through the query's own cell and one ring -- pass 0 here would stage the
+    // same 27 cells to learn the k-th distance it already knew.  Start with the ball of that distance (or, with fewer than k points
+    // found, with the ring of 4 cells).
+    const int first_pass = seed_kth ? 1 : 0;
+    const double seed = (seed_kth && valid) ? seed_kth[slot] : DBL_MAX;
+    for (int pass = first_pass; pass < PASSES; ++pass) {
         if (!__ballot(open)) break;
         int lo0[3], hi0[3];   // this query's box in level-0 cell coordinates
         {
             double kth = DBL_MAX;
 #pragma unroll
             for (int j = 0; j < K; ++j) kth = (j == k - 1) ? bd[j] : kth;
+            if (pass == first_pass && seed_kth) kth = seed;
             const double a[3] = {ax, ay, az};
             if (pass > 0 && kth < DBL_MAX) {
                 const double r = sqrt(kth) * (1.0 + 1e-9) + gv.cell0 * 1e-6;
@@ -578,14 +592,15 @@ __device__ static void knn_tile_one(const pcr_grid_view& gv, knn_tile_lds* L, co
 template <int K, int LPQ, int PASSES, int ROUNDS>
 __global__ void __launch_bounds__(256)
 knn_tile_kernel(pcr_grid_view gv, const double* __restrict__ queries, const unsigned int* __restrict__ order, long long n_static, const unsigned int* __restrict__ count_p,
-                int k, int* __restrict__ idx_out, double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count) {
+                int k, int* __restrict__ idx_out, double* __restrict__ dist_out, int* __restrict__ redo_list, unsigned int* __restrict__ redo_count,
+                const double* __restrict__ seed_kth /* (or null) per entry of `order`: what the first stage knows about the k-th distance */) {
     __shared__ knn_tile_lds s_lds[4];
     constexpr int QPT = 64 / LPQ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long nq = count_p ? (long long)*count_p : n_static;
     const long long n_tiles = (nq + QPT - 1) / QPT;
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
-        knn_tile_one<K, LPQ, PASSES, ROUNDS>(gv, &s_lds[wave], lane, tile, nq, queries, order, k, idx_out, dist_out, redo_list, redo_count);
+        knn_tile_one<K, LPQ, PASSES, ROUNDS>(gv, &s_lds[wave], lane, tile, nq, queries, order, k, idx_out, dist_out, redo_list, redo_count, seed_kth);
         kt_wave_sync();
     }
 }
@@ -693,10 +708,10 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
         const unsigned gw = (unsigned)((q + 3) / 4);
         if (k <= 8)
             hipLaunchKernelGGL((knn_tile_kernel<8, 64, 7, 512>), dim3(gw), dim3(256), 0, ctx->stream, index->view, (const double*)d, (const unsigned int*)(d + o_ord), (long long)q,
-                               (const unsigned int*)nullptr, k, (int*)(d + o_idx), (double*)(d + o_d), (int*)(d + o_redo), (unsigned int*)(d + o_cnt));
+                               (const unsigned int*)nullptr, k, (int*)(d + o_idx), (double*)(d + o_d), (int*)(d + o_redo), (unsigned int*)(d + o_cnt), (const double*)nullptr);
         else
             hipLaunchKernelGGL((knn_tile_kernel<16, 64, 7, 512>), dim3(gw), dim3(256), 0, ctx->stream, index->view, (const double*)d, (const unsigned int*)(d + o_ord), (long long)q,
-                               (const unsigned int*)nullptr, k, (int*)(d + o_idx), (double*)(d + o_d), (int*)(d + o_redo), (unsigned int*)(d + o_cnt));
+                               (const unsigned int*)nullptr, k, (int*)(d + o_idx), (double*)(d + o_d), (int*)(d + o_redo), (unsigned int*)(d + o_cnt), (const double*)nullptr);
         PCR_HIP(ctx, hipGetLastError());
         if ((rc = pcr_wait_flag(ctx, nullptr))) return rc;
         if (*(volatile unsigned int*)(h + o_cnt) != 0u) {
@@ -726,8 +741,10 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
         unsigned int* d_cnt_a = ctx->d_counters + 125;   // queries stage 2 left
         unsigned int* d_cnt_b = ctx->d_counters + 126;   // queries the full block scan left (-> descent)
         unsigned int* d_cnt_d = ctx->d_counters + 127;   // queries stage 1 left
-        pcr_dev_block b_redo2(ctx), b_redo4(ctx);
-        if ((rc = b_redo.alloc(sizeof(int) * q)) || (rc = b_redo2.alloc(sizeof(int) * q)) || (rc = b_redo4.alloc(sizeof(int) * q))) return rc;
+        pcr_dev_block b_redo2(ctx), b_redo4(ctx), b_kth(ctx);
+        if ((rc = b_redo.alloc(sizeof(int) * q)) || (rc = b_redo2.alloc(sizeof(int) * q)) || (rc = b_redo4.alloc(sizeof(int) * q)) || (rc = b_kth.alloc(sizeof(double) * q))) return rc;
+        static const bool no_seed = getenv("PCR_KNN_NO_SEED") != nullptr;   // A/B: the second stage starts over at the query's own 27 cells
+        double* d_kth = no_seed ? nullptr : b_kth.as<double>();
         int *d_redo_a = b_redo.as<int>(), *d_redo_b = b_redo2.as<int>(), *d_redo_d = b_redo4.as<int>();
         PCR_HIP(ctx, hipMemsetAsync(d_cnt_a, 0, 3 * sizeof(unsigned int), ctx->stream));
         const unsigned gb = (unsigned)((q + 255) / 256);
@@ -737,23 +754,23 @@ int pcr_knn(pcr_ctx* ctx, const pcr_index* index, const double* queries, int64_t
             if (gw > 8u * (unsigned)ctx->cu_count) gw = 8u * (unsigned)ctx->cu_count;   // (a fixed grid strides over the list: its length is only known on the device)
             if (k <= 8) {
                 hipLaunchKernelGGL(knn_block_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_d, d_cnt_d,
-                                   (const int*)nullptr, (const unsigned int*)nullptr, lv_first);
+                                   (const int*)nullptr, (const unsigned int*)nullptr, lv_first, d_kth);
                 hipLaunchKernelGGL((knn_tile_kernel<8, 64, 7, 512>), dim3(gw), dim3(256), 0, ctx->stream, index->view, d_q, (const unsigned int*)d_redo_d, (long long)q,
-                                   (const unsigned int*)d_cnt_d, k, d_idx, d_dist, d_redo_a, d_cnt_a);
+                                   (const unsigned int*)d_cnt_d, k, d_idx, d_dist, d_redo_a, d_cnt_a, (const double*)d_kth);
             } else {
                 hipLaunchKernelGGL(knn_block_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_d, d_cnt_d,
-                                   (const int*)nullptr, (const unsigned int*)nullptr, lv_first);
+                                   (const int*)nullptr, (const unsigned int*)nullptr, lv_first, d_kth);
                 hipLaunchKernelGGL((knn_tile_kernel<16, 64, 7, 512>), dim3(gw), dim3(256), 0, ctx->stream, index->view, d_q, (const unsigned int*)d_redo_d, (long long)q,
-                                   (const unsigned int*)d_cnt_d, k, d_idx, d_dist, d_redo_a, d_cnt_a);
+                                   (const unsigned int*)d_cnt_d, k, d_idx, d_dist, d_redo_a, d_cnt_a, (const double*)d_kth);
             }
         }
         const int* todo = no_tiles ? nullptr : d_redo_a;
         if (k <= 8)
             hipLaunchKernelGGL(knn_block_kernel<8>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_b, d_cnt_b, todo,
-                               (const unsigned int*)d_cnt_a, PCR_KNN_LV);
+                               (const unsigned int*)d_cnt_a, PCR_KNN_LV, (double*)nullptr);
         else
             hipLaunchKernelGGL(knn_block_kernel<16>, dim3(gb), dim3(256), 0, ctx->stream, index->view, d_q, (long long)q, k, d_idx, d_dist, d_redo_b, d_cnt_b, todo,
-                               (const unsigned int*)d_cnt_a, PCR_KNN_LV);
+                               (const unsigned int*)d_cnt_a, PCR_KNN_LV, (double*)nullptr);
         unsigned int n_redo[3] = {0, 0, 0};
         { const int rc_n = pcr_d2h_small(ctx, n_redo, d_cnt_a, 3 * sizeof(unsigned int)); if (rc_n) return rc_n; }   // (synchronises; no copy engine)
         static const bool dbg = getenv("PCR_KNN_DEBUG") != nullptr;

@@ -33,3 +33,6 @@ f = lambda v: "best %.1f median %.1f" % (min(v), float(np.median(v)))
 print("%d passes: Python call %s us | C call %s us | device (HIP events over the loop) %s us" % (IT, f(py), f(cc), f(dev)))
 print("   per pass: Python %.2f, C %.2f, device %.2f us; fixed cost of a call over its device time: %.0f us (C), %.0f us (Python)" % (
     min(py) / IT, min(cc) / IT, min(dev) / IT, min(cc) - min(dev), min(py) - min(dev)))
+lg = ctx.pass_log()
+print("   host phases of the last C call (us):", {k: round(float(v), 1) for k, v in lg["host_us"].items()})
+print("   passes by the device clock (us):", " ".join("%.1f" % v for v in lg["tile_us"][:IT]))
