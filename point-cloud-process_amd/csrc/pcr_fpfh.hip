@@ -50,7 +50,12 @@ __device__ static int gather_hybrid(const pcr_grid_view& gv, double qx, double q
     const int cz = cell_coord(qz, gv.lo[2], gv.inv_cell0, &clamped);
     unsigned int s = 0, e = 0;
     bool has = false;
-    if (lane < 27) {
+    if (gv.levels == 0) {
+        // no grid (a cloud of a few thousand points, see brute_view): the whole cloud is the one "cell".  The sphere test, the order
+        // (d^2, row) and the cut at max_nn make the list -- the same list whatever superset of the sphere was scanned.
+        has = lane == 0;
+        e = (unsigned int)gv.n;
+    } else if (lane < 27) {
         const unsigned int nx = (unsigned int)(cx + lane % 3 - 1), ny = (unsigned int)(cy + (lane / 3) % 3 - 1), nz = (unsigned int)(cz + lane / 9 - 1);
         if (nx <= (unsigned int)PCR_COORD_MAX && ny <= (unsigned int)PCR_COORD_MAX && nz <= (unsigned int)PCR_COORD_MAX)
             has = lookup_cell(gv.table[0], gv.mask[0], nx, ny, nz, &s, &e);
@@ -609,18 +614,39 @@ using dev_buf = pcr_dev_block;
 
 int* fail_word(pcr_ctx* ctx) { return (int*)(ctx->d_counters + 116); }
 
+// A cloud of a few thousand points (what the 2 m down-sample of main.py:35 leaves of a scan: 300 - 1 500 points) is searched without
+// an index: two grid builds per scan -- one per radius, ~20 launches each -- cost several times what the neighbourhoods themselves
+// cost, and a wave reads 4 096 records in 64 trips.  The "view" of such a cloud: its records in row order, levels = 0.
+#ifndef PCR_HYBRID_BRUTE_MAX
+#define PCR_HYBRID_BRUTE_MAX 4096
+#endif
+bool brute_view(const pcr_cloud* cloud, pcr_grid_view* v) {
+    static const bool off = getenv("PCR_HYBRID_GRID") != nullptr;   // A/B: always build the grid
+    if (off || cloud->n > PCR_HYBRID_BRUTE_MAX || cloud->morton_sorted) return false;
+    memset(v, 0, sizeof(*v));
+    v->pts = cloud->d;
+    v->n = cloud->n;
+    v->levels = 0;
+    v->cell0 = 1.0; v->inv_cell0 = 1.0;
+    return true;
+}
+
 // normals of a device cloud into d_normals (n,3 by row); enqueued, not waited for (the grid build inside synchronises once);
 // a neighbourhood that cannot be bounded bumps the context's fail word
 int hybrid_normals_device(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int max_nn, int orient, const double* viewpoint, double* d_normals) {
     pcr_index* idx = nullptr;
-    int rc = pcr_index_build(ctx, cloud, PCR_INDEX_GRID, radius, &idx);
-    if (rc) return rc;
-    if (!(idx->view.cell0 >= radius)) { pcr_index_free(ctx, idx); ctx->last_error = "radius too small for the cloud's extent"; return PCR_E_UNSUPPORTED; }
+    pcr_grid_view view;
+    if (!brute_view(cloud, &view)) {
+        int rc = pcr_index_build(ctx, cloud, PCR_INDEX_GRID, radius, &idx);
+        if (rc) return rc;
+        if (!(idx->view.cell0 >= radius)) { pcr_index_free(ctx, idx); ctx->last_error = "radius too small for the cloud's extent"; return PCR_E_UNSUPPORTED; }
+        view = idx->view;
+    }
     const double v[3] = {viewpoint ? viewpoint[0] : 0.0, viewpoint ? viewpoint[1] : 0.0, viewpoint ? viewpoint[2] : 0.0};
-    hipLaunchKernelGGL(hybrid_normals_kernel, dim3((unsigned)cloud->n), dim3(64), 0, ctx->stream, idx->view, (long long)cloud->n, radius * radius, max_nn,
+    hipLaunchKernelGGL(hybrid_normals_kernel, dim3((unsigned)cloud->n), dim3(64), 0, ctx->stream, view, (long long)cloud->n, radius * radius, max_nn,
                        orient, v[0], v[1], v[2], d_normals, fail_word(ctx));
     const hipError_t e = hipGetLastError();
-    pcr_index_free(ctx, idx);   // (stream-ordered)
+    if (idx) pcr_index_free(ctx, idx);   // (stream-ordered)
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
     return PCR_OK;
 }
@@ -635,15 +661,19 @@ int fpfh_device(pcr_ctx* ctx, const pcr_cloud* cloud, const double* d_normals, d
     if ((rc = nbd2.alloc(sizeof(double) * (size_t)max_nn * n))) return rc;
     if ((rc = nbcnt.alloc(sizeof(int) * n))) return rc;
     pcr_index* idx = nullptr;
-    rc = pcr_index_build(ctx, cloud, PCR_INDEX_GRID, radius, &idx);
-    if (rc) return rc;
-    if (!(idx->view.cell0 >= radius)) { pcr_index_free(ctx, idx); ctx->last_error = "radius too small for the cloud's extent"; return PCR_E_UNSUPPORTED; }
-    hipLaunchKernelGGL(spfh_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, idx->view, n, radius * radius, max_nn, d_normals,
+    pcr_grid_view view;
+    if (!brute_view(cloud, &view)) {
+        rc = pcr_index_build(ctx, cloud, PCR_INDEX_GRID, radius, &idx);
+        if (rc) return rc;
+        if (!(idx->view.cell0 >= radius)) { pcr_index_free(ctx, idx); ctx->last_error = "radius too small for the cloud's extent"; return PCR_E_UNSUPPORTED; }
+        view = idx->view;
+    }
+    hipLaunchKernelGGL(spfh_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, view, n, radius * radius, max_nn, d_normals,
                        spfh.as<double>(), nbid.as<unsigned int>(), nbd2.as<double>(), nbcnt.as<int>(), fail_word(ctx));
     hipLaunchKernelGGL(fpfh_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, max_nn, (const double*)spfh.as<double>(),
                        (const unsigned int*)nbid.as<unsigned int>(), (const double*)nbd2.as<double>(), (const int*)nbcnt.as<int>(), d_out);
     const hipError_t e = hipGetLastError();
-    pcr_index_free(ctx, idx);
+    if (idx) pcr_index_free(ctx, idx);
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PCR_E_HIP; }
     return PCR_OK;   // (scratch goes back to the arena stream-ordered)
 }
