@@ -1229,6 +1229,12 @@ extern "C" int pcr_register_pairs(pcr_ctx* const* ctxs, int n_ctx, const pcr_clo
             if (need[(size_t)g]) todo.push_back(g);
         struct prep_slot { pcr_prep* prep = nullptr; pcr_ctx* ctx = nullptr; int rc = PCR_OK; };
         std::vector<prep_slot> preps((size_t)n_clouds);
+        // the whole stage fused on the first context (all scans down-sampled by one sort, every later step one launch for all scans /
+        // all pairs: pcr_global_init_batch); a share that does not fit that path is taken scan by scan and pair by pair below -- same results
+        int fused = todo_pairs.empty() ? PCR_OK : pcr_global_init_batch(ctxs[0], clouds, n_clouds, todo.data(), (int64_t)todo.size(), pairs, todo_pairs.data(),
+                                                                        (int64_t)todo_pairs.size(), global, T_init.data(), 16);
+        if (fused != PCR_OK && fused != PCR_E_UNSUPPORTED) note_error(fused);
+        if (fused == PCR_E_UNSUPPORTED && hard_error.load() == PCR_OK) {
         {
             std::atomic<int64_t> next(0);
             std::atomic<int> next_ctx(0);
@@ -1279,6 +1285,7 @@ extern "C" int pcr_register_pairs(pcr_ctx* const* ctxs, int n_ctx, const pcr_clo
         }
         for (auto& P : preps)
             if (P.prep) { hipSetDevice(P.ctx->device); pcr_prep_free(P.ctx, P.prep); }
+        }
         for (int64_t i = 0; i < n_pairs; ++i) refs[(size_t)i].T0 = &T_init[(size_t)i * 16];
     }
     if (T_init_out) memcpy(T_init_out, T_init.data(), sizeof(double) * 16 * (size_t)n_pairs);

@@ -101,6 +101,7 @@ int pcr_ctx_destroy(pcr_ctx* c) {
     if (c->h_big) hipHostFree(c->h_big);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_down) hipHostFree(c->h_down);
+    if (c->h_init) hipHostFree(c->h_init);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipEventDestroy(c->ev2);

@@ -20,6 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
+#include <atomic>
+#include <thread>
 #include "pcr_grid_dev.h"
 #include "pcr_linalg.h"
 
@@ -188,14 +191,10 @@ __device__ static void smallest_eigvec(const double S[6], double n[3]) {
 }
 
 // ------------------------------------------------------------ hybrid normals
-__global__ void __launch_bounds__(64) hybrid_normals_kernel(pcr_grid_view gv, long long n, double r2, int max_nn, int orient, double vx, double vy,
-                                                            double vz, double* __restrict__ normals /* (n,3) by row */, int* __restrict__ fail) {
-    __shared__ hybrid_lds s_L;
-    nb_entry* const nb = s_L.nb;
-    const long long i = blockIdx.x;
-    if (i >= n) return;
-    const pcr_pt p = gv.pts[i];
-    const int cnt = gather_hybrid(gv, p.x, p.y, p.z, r2, max_nn, &s_L);
+__device__ static void normals_body(const pcr_grid_view& gv, const pcr_pt& p, double r2, int max_nn, int orient, double vx, double vy, double vz,
+                                    double* __restrict__ normals /* (n,3) by row */, int* __restrict__ fail, hybrid_lds* L) {
+    nb_entry* const nb = L->nb;
+    const int cnt = gather_hybrid(gv, p.x, p.y, p.z, r2, max_nn, L);
     if (cnt < 0) { if (threadIdx.x == 0) atomicAdd(fail, 1); return; }
     double nrm[3] = {0.0, 0.0, 1.0};  // Open3D's value for neighbourhoods of fewer than 3 points
     if (cnt >= 3) {
@@ -221,6 +220,41 @@ __global__ void __launch_bounds__(64) hybrid_normals_kernel(pcr_grid_view gv, lo
     }
     const double n0 = nrm[0], n1 = nrm[1], n2 = nrm[2];
     if (threadIdx.x < 3) normals[3 * p.id + threadIdx.x] = threadIdx.x == 0 ? n0 : (threadIdx.x == 1 ? n1 : n2);
+}
+
+__global__ void __launch_bounds__(64) hybrid_normals_kernel(pcr_grid_view gv, long long n, double r2, int max_nn, int orient, double vx, double vy,
+                                                            double vz, double* __restrict__ normals /* (n,3) by row */, int* __restrict__ fail) {
+    __shared__ hybrid_lds s_L;
+    const long long i = blockIdx.x;
+    if (i >= n) return;
+    const pcr_pt p = gv.pts[i];
+    normals_body(gv, p, r2, max_nn, orient, vx, vy, vz, normals, fail, &s_L);
+}
+
+// The down-sampled scans of a chunk, one behind the other (pcr_voxel_downsample_scans): record v belongs to scan vsid[v], whose records
+// are [scan_first[s], scan_first[s + 1]) with id = row within the scan.  A block's "grid view" is its own scan, searched without an index.
+struct scans_view {
+    const pcr_pt* down;
+    const unsigned int* vsid;
+    const unsigned int* scan_first;
+};
+__device__ static inline unsigned int scans_block_view(const scans_view& V, long long i, pcr_grid_view* gv) {
+    const unsigned int s = V.vsid[i], base = V.scan_first[s];
+    gv->pts = V.down + base;
+    gv->n = (long long)(V.scan_first[s + 1] - base);
+    gv->levels = 0;
+    gv->lo[0] = gv->lo[1] = gv->lo[2] = 0.0;
+    gv->cell0 = 1.0; gv->inv_cell0 = 1.0;
+    return base;
+}
+__global__ void __launch_bounds__(64) normals_scans_kernel(scans_view V, long long ng, double r2, int max_nn, double* __restrict__ normals /* (ng,3) */, int* __restrict__ fail) {
+    __shared__ hybrid_lds s_L;
+    const long long i = blockIdx.x;
+    if (i >= ng) return;
+    pcr_grid_view gv;
+    const unsigned int base = scans_block_view(V, i, &gv);
+    const pcr_pt p = V.down[i];
+    normals_body(gv, p, r2, max_nn, 1, 0.0, 0.0, 0.0, normals + 3 * (size_t)base, fail, &s_L);
 }
 
 // ---------------------------------------------------------------------- SPFH
@@ -258,17 +292,12 @@ __device__ static inline int clamp_bin(double x) {
     return h < 0 ? 0 : (h > 10 ? 10 : h);
 }
 
-__global__ void __launch_bounds__(64)
-spfh_kernel(pcr_grid_view gv, long long n, double r2, int max_nn, const double* __restrict__ normals /* by row */, double* __restrict__ spfh /* (n,33) by row */,
-            unsigned int* __restrict__ nb_id /* (n,max_nn) by row */, double* __restrict__ nb_d2, int* __restrict__ nb_cnt, int* __restrict__ fail) {
-    __shared__ hybrid_lds s_L;
-    nb_entry* const nb = s_L.nb;
-    __shared__ int hist[33];
-    const long long i = blockIdx.x;
-    if (i >= n) return;
-    const pcr_pt p = gv.pts[i];
+__device__ static void spfh_body(const pcr_grid_view& gv, const pcr_pt& p, double r2, int max_nn, const double* __restrict__ normals /* by row */,
+                                 double* __restrict__ spfh /* (n,33) by row */, unsigned int* __restrict__ nb_id /* (n,max_nn) by row */, double* __restrict__ nb_d2,
+                                 int* __restrict__ nb_cnt, int* __restrict__ fail, hybrid_lds* L, int* hist /* LDS, 33 */) {
+    nb_entry* const nb = L->nb;
     if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-    const int cnt = gather_hybrid(gv, p.x, p.y, p.z, r2, max_nn, &s_L);  // ends with a barrier
+    const int cnt = gather_hybrid(gv, p.x, p.y, p.z, r2, max_nn, L);  // ends with a barrier
     if (cnt < 0) { if (threadIdx.x == 0) atomicAdd(fail, 1); return; }
     const double p1[3] = {p.x, p.y, p.z};
     const double n1[3] = {normals[3 * p.id], normals[3 * p.id + 1], normals[3 * p.id + 2]};
@@ -298,18 +327,36 @@ spfh_kernel(pcr_grid_view gv, long long n, double r2, int max_nn, const double* 
     }
 }
 
+__global__ void __launch_bounds__(64)
+spfh_kernel(pcr_grid_view gv, long long n, double r2, int max_nn, const double* __restrict__ normals /* by row */, double* __restrict__ spfh /* (n,33) by row */,
+            unsigned int* __restrict__ nb_id /* (n,max_nn) by row */, double* __restrict__ nb_d2, int* __restrict__ nb_cnt, int* __restrict__ fail) {
+    __shared__ hybrid_lds s_L;
+    __shared__ int hist[33];
+    const long long i = blockIdx.x;
+    if (i >= n) return;
+    const pcr_pt p = gv.pts[i];
+    spfh_body(gv, p, r2, max_nn, normals, spfh, nb_id, nb_d2, nb_cnt, fail, &s_L, hist);
+}
+
+__global__ void __launch_bounds__(64)
+spfh_scans_kernel(scans_view V, long long ng, double r2, int max_nn, const double* __restrict__ normals, double* __restrict__ spfh, unsigned int* __restrict__ nb_id,
+                  double* __restrict__ nb_d2, int* __restrict__ nb_cnt, int* __restrict__ fail) {
+    __shared__ hybrid_lds s_L;
+    __shared__ int hist[33];
+    const long long i = blockIdx.x;
+    if (i >= ng) return;
+    pcr_grid_view gv;
+    const size_t base = scans_block_view(V, i, &gv);
+    const pcr_pt p = V.down[i];
+    spfh_body(gv, p, r2, max_nn, normals + 3 * base, spfh + 33 * base, nb_id + base * (size_t)max_nn, nb_d2 + base * (size_t)max_nn, nb_cnt + base, fail, &s_L, hist);
+}
+
 // ---------------------------------------------------------------------- FPFH
 // One wave per point, lane = histogram bin (33 of 64).  The neighbour list (row, d^2) goes through LDS first, so the SPFH rows
 // of four neighbours are requested together instead of one dependent chain id -> row per neighbour; every term is spfh / d^2
 // (a true division, as in Open3D); the three renormalising sums are taken over the lanes of each 11-bin block at the end.
-__global__ void __launch_bounds__(64)
-fpfh_kernel(long long n, int max_nn, const double* __restrict__ spfh, const unsigned int* __restrict__ nb_id, const double* __restrict__ nb_d2,
-            const int* __restrict__ nb_cnt, double* __restrict__ fpfh /* (n,33) by row */) {
-    __shared__ unsigned int s_id[NB_CAP];
-    __shared__ double s_d2[NB_CAP];
-    __shared__ double s_acc[33];
-    const long long i = blockIdx.x;
-    if (i >= n) return;
+__device__ static void fpfh_body(const long long i, int max_nn, const double* __restrict__ spfh, const unsigned int* __restrict__ nb_id, const double* __restrict__ nb_d2,
+                                 const int* __restrict__ nb_cnt, double* __restrict__ fpfh /* (n,33) by row */, unsigned int* s_id, double* s_d2, double* s_acc) {
     const int cnt = nb_cnt[i];
     const int lane = threadIdx.x;
     for (int k = lane; k < cnt; k += 64) { s_id[k] = nb_id[i * max_nn + k]; s_d2[k] = nb_d2[i * max_nn + k]; }
@@ -345,6 +392,30 @@ fpfh_kernel(long long n, int max_nn, const double* __restrict__ spfh, const unsi
     }
 }
 
+__global__ void __launch_bounds__(64)
+fpfh_kernel(long long n, int max_nn, const double* __restrict__ spfh, const unsigned int* __restrict__ nb_id, const double* __restrict__ nb_d2,
+            const int* __restrict__ nb_cnt, double* __restrict__ fpfh /* (n,33) by row */) {
+    __shared__ unsigned int s_id[NB_CAP];
+    __shared__ double s_d2[NB_CAP];
+    __shared__ double s_acc[33];
+    const long long i = blockIdx.x;
+    if (i >= n) return;
+    fpfh_body(i, max_nn, spfh, nb_id, nb_d2, nb_cnt, fpfh, s_id, s_d2, s_acc);
+}
+
+// (the records of a scan sit in row order: record base + r is row r)
+__global__ void __launch_bounds__(64)
+fpfh_scans_kernel(scans_view V, long long ng, int max_nn, const double* __restrict__ spfh, const unsigned int* __restrict__ nb_id, const double* __restrict__ nb_d2,
+                  const int* __restrict__ nb_cnt, double* __restrict__ fpfh) {
+    __shared__ unsigned int s_id[NB_CAP];
+    __shared__ double s_d2[NB_CAP];
+    __shared__ double s_acc[33];
+    const long long i = blockIdx.x;
+    if (i >= ng) return;
+    const size_t base = V.scan_first[V.vsid[i]];
+    fpfh_body(i - (long long)base, max_nn, spfh + 33 * base, nb_id + base * (size_t)max_nn, nb_d2 + base * (size_t)max_nn, nb_cnt + base, fpfh + 33 * base, s_id, s_d2, s_acc);
+}
+
 // ----------------------------------------------------------- feature matching
 // One thread per query row, target rows staged through LDS in tiles; squared L2 summed over the
 // dimensions in order; ties to the lowest target row.
@@ -352,11 +423,10 @@ constexpr int FM_TILE = 32;
 // grid = (query blocks, target splits): block (bx, by) scans targets [by * per, (by + 1) * per); a small merge kernel
 // takes the minimum over the splits (ascending split order + strict comparison keeps the lowest row on ties).
 template <int DIM>
-__global__ void __launch_bounds__(256) feature_match_kernel(const double* __restrict__ A, long long na, const double* __restrict__ B, long long nb, int dim_rt,
-                                                             long long per, int* __restrict__ idx_out, double* __restrict__ d2_out) {
-    extern __shared__ double tile[];  // FM_TILE * dim
+__device__ static void feature_match_body(const double* __restrict__ A, long long na, const double* __restrict__ B, long long nb, int dim_rt, long long per,
+                                          int* __restrict__ idx_out, double* __restrict__ d2_out, const unsigned int bx, const unsigned int by, double* tile /* LDS: FM_TILE * dim */) {
     const int dim = DIM > 0 ? DIM : dim_rt;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)bx * blockDim.x + threadIdx.x;
     const bool live = i < na;
     double a[DIM > 0 ? DIM : 1];
     if (DIM > 0 && live) {
@@ -365,7 +435,7 @@ __global__ void __launch_bounds__(256) feature_match_kernel(const double* __rest
     }
     double best = DBL_MAX;
     int bidx = -1;
-    const long long tb = (long long)blockIdx.y * per, te = (tb + per < nb) ? tb + per : nb;
+    const long long tb = (long long)by * per, te = (tb + per < nb) ? tb + per : nb;
     for (long long t0 = tb; t0 < te; t0 += FM_TILE) {
         const int rows = (int)((te - t0) < FM_TILE ? (te - t0) : FM_TILE);
         __syncthreads();
@@ -383,12 +453,18 @@ __global__ void __launch_bounds__(256) feature_match_kernel(const double* __rest
             if (s < best) { best = s; bidx = (int)(t0 + r); }
         }
     }
-    if (live) { idx_out[(long long)blockIdx.y * na + i] = bidx; d2_out[(long long)blockIdx.y * na + i] = best; }
+    if (live) { idx_out[(long long)by * na + i] = bidx; d2_out[(long long)by * na + i] = best; }
+}
+template <int DIM>
+__global__ void __launch_bounds__(256) feature_match_kernel(const double* __restrict__ A, long long na, const double* __restrict__ B, long long nb, int dim_rt,
+                                                             long long per, int* __restrict__ idx_out, double* __restrict__ d2_out) {
+    extern __shared__ double tile[];  // FM_TILE * dim
+    feature_match_body<DIM>(A, na, B, nb, dim_rt, per, idx_out, d2_out, blockIdx.x, blockIdx.y, tile);
 }
 
-__global__ void feature_match_merge_kernel(const int* __restrict__ cidx, const double* __restrict__ cd2, long long na, int splits,
-                                           int* __restrict__ idx_out, double* __restrict__ d2_out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ static void feature_match_merge_body(const int* __restrict__ cidx, const double* __restrict__ cd2, long long na, int splits, int* __restrict__ idx_out,
+                                                double* __restrict__ d2_out, const unsigned int bx) {
+    const long long i = (long long)bx * blockDim.x + threadIdx.x;
     if (i >= na) return;
     double best = DBL_MAX;
     int bidx = -1;
@@ -399,6 +475,10 @@ __global__ void feature_match_merge_kernel(const int* __restrict__ cidx, const d
     }
     idx_out[i] = bidx;
     d2_out[i] = best;
+}
+__global__ void feature_match_merge_kernel(const int* __restrict__ cidx, const double* __restrict__ cd2, long long na, int splits,
+                                           int* __restrict__ idx_out, double* __restrict__ d2_out) {
+    feature_match_merge_body(cidx, cd2, na, splits, idx_out, d2_out, blockIdx.x);
 }
 
 // --------------------------------------------------------------------- RANSAC
@@ -434,9 +514,8 @@ __host__ __device__ static inline unsigned long long mix64(unsigned long long x)
 }
 
 // one wave per hypothesis; out: inl[h] (-1 = rejected by a checker), err2[h], T[h][12]
-__global__ void __launch_bounds__(64) ransac_kernel(ransac_args a, const ransac_state* __restrict__ st, int* __restrict__ inl, double* __restrict__ err2,
-                                                    double* __restrict__ Tout) {
-    const int h = blockIdx.x;
+__device__ static void ransac_eval(const ransac_args& a, const ransac_state* __restrict__ st, int* __restrict__ inl, double* __restrict__ err2,
+                                   double* __restrict__ Tout, const int h) {
     if (h >= a.n_iter || st->stop) return;
     const int m = st->m;
     const unsigned long long itr = (unsigned long long)(a.first_iter + h);
@@ -511,12 +590,17 @@ __global__ void __launch_bounds__(64) ransac_kernel(ransac_args a, const ransac_
     }
 }
 
+__global__ void __launch_bounds__(64) ransac_kernel(ransac_args a, const ransac_state* __restrict__ st, int* __restrict__ inl, double* __restrict__ err2,
+                                                    double* __restrict__ Tout) {
+    ransac_eval(a, st, inl, err2, Tout, (int)blockIdx.x);
+}
+
 // ONE wave: the sequential loop over the batch -- iteration order, running best (IsBetterRANSACThan: higher fitness, or equal
 // fitness and lower rmse; the initial best is (0, 0)), exit_itr = min(exit_itr, ceil(log(1 - confidence) / log(1 - fitness^3)))
 // after every improvement, stop at the first iteration >= exit_itr -- 64 iterations at a time: inside a chunk the NEXT improvement
 // is the first lane that beats the current best (the order is a strict weak order, so nobody in front of it can beat the new best).
-__global__ void __launch_bounds__(64) ransac_walk_kernel(ransac_args a, ransac_state* __restrict__ st, const int* __restrict__ inl, const double* __restrict__ err2,
-                                                         const double* __restrict__ Tout) {
+__device__ static void ransac_walk(const ransac_args& a, ransac_state* __restrict__ st, const int* __restrict__ inl, const double* __restrict__ err2,
+                                   const double* __restrict__ Tout) {
     if (st->stop) return;
     const int lane = threadIdx.x;
     const int m = st->m;
@@ -560,7 +644,12 @@ __global__ void __launch_bounds__(64) ransac_walk_kernel(ransac_args a, ransac_s
     }
 }
 
-__global__ void ransac_init_kernel(ransac_state* st, const int* m_p, int max_iteration) {
+__global__ void __launch_bounds__(64) ransac_walk_kernel(ransac_args a, ransac_state* __restrict__ st, const int* __restrict__ inl, const double* __restrict__ err2,
+                                                         const double* __restrict__ Tout) {
+    ransac_walk(a, st, inl, err2, Tout);
+}
+
+__device__ static void ransac_init(ransac_state* st, const int* m_p, int max_iteration) {
     if (threadIdx.x != 0) return;
     ransac_state z;
     z.best_fit = 0.0; z.best_rmse = 0.0;
@@ -572,11 +661,16 @@ __global__ void ransac_init_kernel(ransac_state* st, const int* m_p, int max_ite
     *st = z;
 }
 
+__global__ void ransac_init_kernel(ransac_state* st, const int* m_p, int max_iteration) { ransac_init(st, m_p, max_iteration); }
+
 // correspondence set of registration_ransac_based_on_feature_matching: (i, ij[i]) for every source row, kept when mutual
 // (ji[ij[i]] == i); when fewer than `min_mutual` survive, Open3D falls back to the one-way set.  ONE block, rows in order.
-__global__ void __launch_bounds__(256) corr_build_kernel(const int* __restrict__ ij, const int* __restrict__ ji, int na, int mutual, int min_mutual,
-                                                         int* __restrict__ corr, int* __restrict__ m_out) {
-    __shared__ int s_w[4], s_total, s_use;
+struct corr_lds { int w[4], total, use; };
+__device__ static void corr_build_body(const int* __restrict__ ij, const int* __restrict__ ji, int na, int mutual, int min_mutual, int* __restrict__ corr,
+                                       int* __restrict__ m_out, corr_lds* L) {
+    int* const s_w = L->w;
+    int& s_total = L->total;
+    int& s_use = L->use;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_total = 0;
     __syncthreads();
@@ -606,6 +700,75 @@ __global__ void __launch_bounds__(256) corr_build_kernel(const int* __restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) *m_out = base;
+}
+__global__ void __launch_bounds__(256) corr_build_kernel(const int* __restrict__ ij, const int* __restrict__ ji, int na, int mutual, int min_mutual,
+                                                         int* __restrict__ corr, int* __restrict__ m_out) {
+    __shared__ corr_lds s_L;
+    corr_build_body(ij, ji, na, mutual, min_mutual, corr, m_out, &s_L);
+}
+
+// ------------------------------------------------------------------------------------------------ every pair of a share at once
+// The same stages with one launch for ALL pairs (a job = one pair; blockIdx.y / .z picks it): a pair alone is ten launches of a few
+// microseconds of work each, and a share of the reference's pair loop (main.py:190-216) is hundreds of pairs.
+struct init_job {
+    const pcr_pt *src, *tgt;          // down-sampled records by row
+    const double *fa, *fb;            // FPFH (n,33)
+    int na, nb;
+    int *ij, *ji;                     // nearest target row of every source row, and the other way
+    double *dab, *dba;
+    int *ci_ab, *ci_ba;               // per-split candidates (splits x n)
+    double *cd_ab, *cd_ba;
+    int *corr, *m;                    // (na,2) + count
+    ransac_state* st;
+    int* inl;                         // hypothesis scratch of a batch
+    double *err2, *Tout;
+    unsigned long long seed;
+};
+constexpr int JOB_SPLITS = 8;
+__device__ static inline long long job_per(long long nb) { return ((nb + JOB_SPLITS - 1) / JOB_SPLITS + FM_TILE - 1) / FM_TILE * FM_TILE; }
+
+__global__ void __launch_bounds__(256) feature_match_jobs_kernel(const init_job* __restrict__ jobs, int mutual) {
+    __shared__ double tile[FM_TILE * 33];
+    const init_job J = jobs[blockIdx.z >> 1];
+    const bool back = (blockIdx.z & 1) != 0;
+    if (back && !mutual) return;
+    const long long na = back ? J.nb : J.na, nb = back ? J.na : J.nb;
+    if ((long long)blockIdx.x * 256 >= na) return;   // (the whole block)
+    feature_match_body<33>(back ? J.fb : J.fa, na, back ? J.fa : J.fb, nb, 33, job_per(nb), back ? J.ci_ba : J.ci_ab, back ? J.cd_ba : J.cd_ab, blockIdx.x, blockIdx.y, tile);
+}
+__global__ void __launch_bounds__(256) feature_match_merge_jobs_kernel(const init_job* __restrict__ jobs, int mutual) {
+    const init_job J = jobs[blockIdx.y >> 1];
+    const bool back = (blockIdx.y & 1) != 0;
+    if (back && !mutual) return;
+    const long long na = back ? J.nb : J.na;
+    feature_match_merge_body(back ? J.ci_ba : J.ci_ab, back ? J.cd_ba : J.cd_ab, na, JOB_SPLITS, back ? J.ji : J.ij, back ? J.dba : J.dab, blockIdx.x);
+}
+__global__ void __launch_bounds__(256) corr_build_jobs_kernel(const init_job* __restrict__ jobs, int mutual, int min_mutual, int max_iteration) {
+    __shared__ corr_lds s_L;
+    const init_job J = jobs[blockIdx.x];
+    corr_build_body(J.ij, J.ji, J.na, mutual, min_mutual, J.corr, J.m, &s_L);
+    __syncthreads();   // (the count is written by thread 0, which also initialises the loop state)
+    ransac_init(J.st, J.m, max_iteration);
+}
+struct ransac_common { double edge_sim, max_dist, confidence; int check_distance, max_iteration, first_iter, n_iter; };
+__device__ static inline ransac_args job_args(const init_job& J, const ransac_common& c) {
+    ransac_args a;
+    a.src = J.src; a.tgt = J.tgt; a.corr = J.corr;
+    a.first_iter = c.first_iter; a.n_iter = c.n_iter;
+    a.seed = J.seed; a.edge_sim = c.edge_sim; a.max_dist = c.max_dist; a.check_distance = c.check_distance;
+    a.max_iteration = c.max_iteration; a.confidence = c.confidence;
+    return a;
+}
+// active: the jobs still running (indices into jobs), or null = all
+__global__ void __launch_bounds__(64) ransac_jobs_kernel(const init_job* __restrict__ jobs, const int* __restrict__ active, ransac_common c) {
+    const init_job J = jobs[active ? active[blockIdx.y] : blockIdx.y];
+    const ransac_args a = job_args(J, c);
+    ransac_eval(a, J.st, J.inl, J.err2, J.Tout, (int)blockIdx.x);
+}
+__global__ void __launch_bounds__(64) ransac_walk_jobs_kernel(const init_job* __restrict__ jobs, const int* __restrict__ active, ransac_common c) {
+    const init_job J = jobs[active ? active[blockIdx.x] : blockIdx.x];
+    const ransac_args a = job_args(J, c);
+    ransac_walk(a, J.st, J.inl, J.err2, J.Tout);
 }
 
 // ------------------------------------------------------------------ host side
@@ -849,6 +1012,263 @@ int pcr_global_registration(pcr_ctx* ctx, const pcr_prep* source, const pcr_prep
     }
     return ransac_device(ctx, s_rows, t_rows, corr.as<int>(), d_m, prm, res);
 }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ the pair loop's initialisation, fused
+// prepare_dataset + execute_global_registration (Registration/main.py:197-203) for a whole share of pairs on ONE context: the scans
+// are packed into pinned memory by a few host threads and copied once; ONE sort down-samples all of them (pcr_voxel_downsample_scans);
+// normals, SPFH and FPFH are one launch each over every down-sampled point of the chunk (a block's search space is its own scan); matching,
+// correspondence sets and the RANSAC loop run for all pairs side by side.  Same arithmetic, same order, same seeds as pcr_preprocess +
+// pcr_global_registration pair by pair: the results are bit for bit those (tests/test_gpu_global_init.py).
+// Returns PCR_E_UNSUPPORTED when the share does not fit this path (a down-sampled scan above PCR_HYBRID_BRUTE_MAX points, a neighbourhood
+// that cannot be bounded, extents too large for the packed key): the caller then takes the scans one by one.
+namespace {
+struct scan_chunk {
+    pcr_pt* down = nullptr;
+    double* fpfh = nullptr;
+    unsigned int* vsid = nullptr;
+    unsigned int* scan_first = nullptr;
+    int64_t ng = 0;
+    int n_scans = 0;
+    std::vector<unsigned int> first;   // host copy of scan_first
+};
+struct scan_slot { int chunk = -1, local = 0; };
+
+template <typename F>
+void parallel_for(int64_t n, int threads, F&& fn) {
+    if (threads > (int)n) threads = (int)n;
+    if (threads <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int64_t> next(0);
+    auto worker = [&]() { for (;;) { const int64_t i = next.fetch_add(1); if (i >= n) break; fn(i); } };
+    std::vector<std::thread> pool;
+    try { for (int t = 1; t < threads; ++t) pool.emplace_back(worker); } catch (...) {}   // (a refused thread: the others do its share)
+    worker();
+    for (auto& th : pool) th.join();
+}
+}  // namespace
+
+int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_clouds, const int64_t* scans, int64_t n_scans, const pcr_pair_ref* pairs,
+                          const int64_t* todo, int64_t n_todo, const pcr_global_params* g, double* T_init, int host_threads) {
+    if (!ctx || !clouds || !scans || !pairs || !todo || !g || !T_init || n_scans < 1 || n_todo < 1) return PCR_E_INVALID;
+    if (!(g->voxel_size > 0) || !(g->normal_radius > 0) || !(g->fpfh_radius > 0) || g->normal_max_nn < 1 || g->normal_max_nn > NB_CAP || g->fpfh_max_nn < 2 ||
+        g->fpfh_max_nn > NB_CAP || g->ransac.max_iteration < 1 || !(g->ransac.max_distance > 0))
+        return PCR_E_INVALID;
+    static const bool off = getenv("PCR_INIT_PER_SCAN") != nullptr;   // A/B: always the scans one by one
+    if (off) return PCR_E_UNSUPPORTED;
+    hipSetDevice(ctx->device);
+    static const bool timing = getenv("PCR_INIT_TIMING") != nullptr;   // diagnostics: milliseconds per stage to stderr (synchronises after every stage)
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "pcr_global_init_batch: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    constexpr int64_t CHUNK_PTS = 16ll << 20;
+    constexpr int CHUNK_SCANS = 2048;
+    std::vector<scan_slot> slot((size_t)n_clouds);
+    std::vector<scan_chunk> chunks;
+    int rc = PCR_OK;
+    auto release = [&]() {
+        for (auto& c : chunks) {
+            if (c.down) pcr_dev_free(ctx, c.down, sizeof(pcr_pt) * (size_t)(c.ng > 0 ? c.ng : 1));
+            if (c.vsid) pcr_dev_free(ctx, c.vsid, 4 * (size_t)(c.ng > 0 ? c.ng : 1));
+            if (c.scan_first) pcr_dev_free(ctx, c.scan_first, 4 * (size_t)(c.n_scans + 1));
+            if (c.fpfh) pcr_dev_free(ctx, c.fpfh, sizeof(double) * 33 * (size_t)(c.ng > 0 ? c.ng : 1));
+        }
+        chunks.clear();
+    };
+    // ---------------------------------------------------------------- the scans, chunk by chunk
+    for (int64_t s0 = 0; s0 < n_scans && rc == PCR_OK;) {
+        int64_t s1 = s0, pts = 0;
+        while (s1 < n_scans && s1 - s0 < CHUNK_SCANS) {
+            const int64_t n = clouds[scans[s1]].n;
+            if (n < 0 || n > 0x7fffffffll || clouds[scans[s1]].stride < 3 || (n > 0 && !clouds[scans[s1]].xyz)) { release(); return PCR_E_INVALID; }
+            if (pts > 0 && pts + n > CHUNK_PTS) break;
+            pts += n;
+            ++s1;
+        }
+        // (an empty scan stays without a slot: its pairs keep the identity, as when pcr_cloud_upload_f32 says PCR_E_EMPTY)
+        std::vector<pcr_down_scan> ds;
+        std::vector<int64_t> who;
+        unsigned int at = 0;
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t n = clouds[scans[s]].n;
+            if (n == 0) continue;
+            pcr_down_scan d;
+            d.first_pt = at; d.n_pts = (unsigned int)n;
+            at += (unsigned int)n;
+            ds.push_back(d);
+            who.push_back(scans[s]);
+        }
+        s0 = s1;
+        if (ds.empty()) continue;
+        const size_t bytes = 12 * (size_t)at;
+        if (ctx->h_init_bytes < bytes) {
+            if (ctx->h_init) hipHostFree(ctx->h_init);
+            ctx->h_init = nullptr; ctx->h_init_bytes = 0;
+            if (hipHostMalloc(&ctx->h_init, bytes, hipHostMallocDefault) != hipSuccess) { release(); ctx->last_error = "no pinned memory for the scans"; return PCR_E_NOMEM; }
+            ctx->h_init_bytes = bytes;
+        }
+        float* const h_xyz = (float*)ctx->h_init;
+        parallel_for((int64_t)ds.size(), host_threads, [&](int64_t k) {
+            const pcr_cloud_ref& C = clouds[who[(size_t)k]];
+            float* dst = h_xyz + 3 * (size_t)ds[(size_t)k].first_pt;
+            float lo[3] = {C.xyz[0], C.xyz[1], C.xyz[2]}, hi[3] = {C.xyz[0], C.xyz[1], C.xyz[2]};
+            for (int64_t i = 0; i < C.n; ++i) {
+                const float* r = C.xyz + (size_t)i * (size_t)C.stride;
+                dst[3 * i] = r[0]; dst[3 * i + 1] = r[1]; dst[3 * i + 2] = r[2];
+                for (int d = 0; d < 3; ++d) { lo[d] = r[d] < lo[d] ? r[d] : lo[d]; hi[d] = r[d] > hi[d] ? r[d] : hi[d]; }
+            }
+            for (int d = 0; d < 3; ++d) { ds[(size_t)k].mn[d] = (double)lo[d]; ds[(size_t)k].mx[d] = (double)hi[d]; }
+        });
+        lap("pack (host threads)");
+        pcr_dev_block b_xyz(ctx);
+        if ((rc = b_xyz.alloc(bytes))) break;
+        if (hipMemcpyAsync(b_xyz.p, h_xyz, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
+        lap("copy to the device");
+        chunks.emplace_back();
+        scan_chunk& c = chunks.back();
+        c.n_scans = (int)ds.size();
+        c.first.assign(ds.size() + 1, 0u);
+        rc = pcr_voxel_downsample_scans(ctx, (const float*)b_xyz.p, (int64_t)at, ds.data(), c.n_scans, g->voxel_size, &c.down, &c.vsid, &c.scan_first, c.first.data(), &c.ng);   // (synchronises)
+        if (rc) break;
+        lap("down-sample (all scans)");
+        for (int k = 0; k < c.n_scans; ++k) {
+            if (c.first[(size_t)k + 1] - c.first[(size_t)k] > (unsigned int)PCR_HYBRID_BRUTE_MAX) { rc = PCR_E_UNSUPPORTED; break; }
+            slot[(size_t)who[(size_t)k]].chunk = (int)chunks.size() - 1;
+            slot[(size_t)who[(size_t)k]].local = k;
+        }
+        if (rc) break;
+        const size_t ng = (size_t)c.ng;
+        pcr_dev_block b_nrm(ctx), b_spfh(ctx), b_id(ctx), b_d2(ctx), b_cnt(ctx);
+        if ((rc = pcr_dev_alloc(ctx, sizeof(double) * 33 * ng, (void**)&c.fpfh)) || (rc = b_nrm.alloc(sizeof(double) * 3 * ng)) || (rc = b_spfh.alloc(sizeof(double) * 33 * ng)) ||
+            (rc = b_id.alloc(sizeof(unsigned int) * (size_t)g->fpfh_max_nn * ng)) || (rc = b_d2.alloc(sizeof(double) * (size_t)g->fpfh_max_nn * ng)) || (rc = b_cnt.alloc(sizeof(int) * ng)))
+            break;
+        const scans_view V{c.down, c.vsid, c.scan_first};
+        hipLaunchKernelGGL(normals_scans_kernel, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->normal_radius * g->normal_radius, g->normal_max_nn,
+                           b_nrm.as<double>(), fail_word(ctx));
+        hipLaunchKernelGGL(spfh_scans_kernel, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_radius * g->fpfh_radius, g->fpfh_max_nn,
+                           (const double*)b_nrm.as<double>(), b_spfh.as<double>(), b_id.as<unsigned int>(), b_d2.as<double>(), b_cnt.as<int>(), fail_word(ctx));
+        hipLaunchKernelGGL(fpfh_scans_kernel, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_max_nn, (const double*)b_spfh.as<double>(),
+                           (const unsigned int*)b_id.as<unsigned int>(), (const double*)b_d2.as<double>(), (const int*)b_cnt.as<int>(), c.fpfh);
+        if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
+        rc = read_fail(ctx);   // (synchronises: the chunk's scratch and the pinned block are free for the next chunk)
+        lap("normals + SPFH + FPFH");
+    }
+    if (rc) { pcr_sync(ctx->stream); release(); return rc; }
+    // ---------------------------------------------------------------- the pairs
+    const int mutual = g->mutual_filter ? 1 : 0;
+    constexpr int PAIR_CHUNK = 512, FIRST = 4096, BATCH = 16384;
+    for (int64_t p0 = 0; p0 < n_todo && rc == PCR_OK; p0 += PAIR_CHUNK) {
+        const int64_t p1 = p0 + PAIR_CHUNK < n_todo ? p0 + PAIR_CHUNK : n_todo;
+        std::vector<init_job> jobs;
+        std::vector<int64_t> job_pair;
+        size_t n_i = 0, n_d = 0;   // ints / doubles of the pool
+        int max_n = 1;
+        for (int64_t t = p0; t < p1; ++t) {
+            const pcr_pair_ref& P = pairs[todo[t]];
+            const scan_slot &S = slot[(size_t)P.src], &T = slot[(size_t)P.tgt];
+            if (S.chunk < 0 || T.chunk < 0) continue;   // an empty scan: identity
+            const scan_chunk &cs = chunks[(size_t)S.chunk], &ct = chunks[(size_t)T.chunk];
+            init_job J;
+            memset(&J, 0, sizeof(J));
+            const unsigned int fs = cs.first[(size_t)S.local], ft = ct.first[(size_t)T.local];
+            J.na = (int)(cs.first[(size_t)S.local + 1] - fs);
+            J.nb = (int)(ct.first[(size_t)T.local + 1] - ft);
+            if (J.na <= 0 || J.nb <= 0) continue;
+            J.src = cs.down + fs; J.tgt = ct.down + ft;
+            J.fa = cs.fpfh + 33 * (size_t)fs; J.fb = ct.fpfh + 33 * (size_t)ft;
+            J.seed = g->ransac.seed;
+            // pool offsets (resolved below): ij na | ji nb | ci_ab S*na | ci_ba S*nb | corr 2 na + 4 | inl BATCH   (ints)
+            //                                dab na | dba nb | cd_ab S*na | cd_ba S*nb | err2 BATCH | Tout 12 BATCH | state   (doubles)
+            n_i += (size_t)(1 + JOB_SPLITS + 2) * J.na + (size_t)(1 + JOB_SPLITS) * J.nb + 4 + BATCH;
+            n_d += (size_t)(1 + JOB_SPLITS) * (J.na + J.nb) + 13 * (size_t)BATCH;
+            if (J.na > max_n) max_n = J.na;
+            if (J.nb > max_n) max_n = J.nb;
+            jobs.push_back(J);
+            job_pair.push_back(todo[t]);
+        }
+        const int nj = (int)jobs.size();
+        if (nj == 0) continue;
+        pcr_dev_block b_i(ctx), b_d(ctx), b_jobs(ctx), b_act(ctx), b_st(ctx);
+        if ((rc = b_i.alloc(4 * n_i)) || (rc = b_d.alloc(8 * n_d)) || (rc = b_jobs.alloc(sizeof(init_job) * nj)) || (rc = b_act.alloc(4 * (size_t)nj)) ||
+            (rc = b_st.alloc(sizeof(ransac_state) * (size_t)nj)))
+            break;
+        {
+            int* pi = b_i.as<int>();
+            double* pd = b_d.as<double>();
+            ransac_state* ps = b_st.as<ransac_state>();
+            for (auto& J : jobs) {
+                J.st = ps++;
+                J.ij = pi; pi += J.na;
+                J.ji = pi; pi += J.nb;
+                J.ci_ab = pi; pi += (size_t)JOB_SPLITS * J.na;
+                J.ci_ba = pi; pi += (size_t)JOB_SPLITS * J.nb;
+                J.corr = pi; J.m = pi + 2 * (size_t)J.na; pi += 2 * (size_t)J.na + 4;
+                J.inl = pi; pi += BATCH;
+                J.dab = pd; pd += J.na;
+                J.dba = pd; pd += J.nb;
+                J.cd_ab = pd; pd += (size_t)JOB_SPLITS * J.na;
+                J.cd_ba = pd; pd += (size_t)JOB_SPLITS * J.nb;
+                J.err2 = pd; pd += BATCH;
+                J.Tout = pd; pd += 12 * (size_t)BATCH;
+            }
+        }
+        if (hipMemcpyAsync(b_jobs.p, jobs.data(), sizeof(init_job) * nj, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
+        const init_job* d_jobs = b_jobs.as<const init_job>();
+        const unsigned qb = (unsigned)((max_n + 255) / 256);
+        hipLaunchKernelGGL(feature_match_jobs_kernel, dim3(qb, JOB_SPLITS, 2 * nj), dim3(256), 0, ctx->stream, d_jobs, mutual);
+        hipLaunchKernelGGL(feature_match_merge_jobs_kernel, dim3(qb, 2 * nj), dim3(256), 0, ctx->stream, d_jobs, mutual);
+        hipLaunchKernelGGL(corr_build_jobs_kernel, dim3(nj), dim3(256), 0, ctx->stream, d_jobs, mutual, 9, g->ransac.max_iteration);
+        lap("matching + correspondences");
+        ransac_common rcmn;
+        rcmn.edge_sim = g->ransac.edge_similarity; rcmn.max_dist = g->ransac.max_distance; rcmn.confidence = g->ransac.confidence;
+        rcmn.check_distance = g->ransac.check_distance; rcmn.max_iteration = g->ransac.max_iteration;
+        std::vector<ransac_state> st((size_t)nj);
+        std::vector<int> active;
+        long long done = 0;
+        // the first 4 096 iterations for every pair (most registrations exit within the first thousand), then 16 384 at a time for
+        // the pairs that are still running
+        for (int round = 0; done < g->ransac.max_iteration && rc == PCR_OK; ++round) {
+            const long long want = round == 0 ? FIRST : BATCH;
+            const int nb = (int)((g->ransac.max_iteration - done) < want ? (g->ransac.max_iteration - done) : want);
+            rcmn.first_iter = (int)done; rcmn.n_iter = nb;
+            const int n_run = round == 0 ? nj : (int)active.size();
+            const int* d_act = round == 0 ? nullptr : b_act.as<const int>();
+            if (round > 0 && hipMemcpyAsync(b_act.p, active.data(), 4 * (size_t)n_run, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
+            hipLaunchKernelGGL(ransac_jobs_kernel, dim3(nb, n_run), dim3(64), 0, ctx->stream, d_jobs, d_act, rcmn);
+            hipLaunchKernelGGL(ransac_walk_jobs_kernel, dim3(n_run), dim3(64), 0, ctx->stream, d_jobs, d_act, rcmn);
+            if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
+            done += nb;
+            if ((rc = pcr_d2h_staged(ctx, st.data(), b_st.p, sizeof(ransac_state) * (size_t)nj))) break;   // every job's state, one read (synchronises)
+            std::vector<int> next;
+            for (int j = 0; j < nj; ++j)
+                if (!st[(size_t)j].stop) next.push_back(j);
+            active.swap(next);
+            lap("RANSAC round");
+            if (active.empty()) break;
+        }
+        if (rc) break;
+        for (int j = 0; j < nj; ++j) {
+            const ransac_state& h = st[(size_t)j];
+            if (h.m < 3 || h.best_itr < 0) continue;   // PCR_E_TOO_FEW_ASSOC pair by pair: identity
+            double* T = T_init + 16 * (size_t)job_pair[(size_t)j];
+            for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) T[4 * a + b] = h.bestT[3 * a + b];
+                T[4 * a + 3] = h.bestT[9 + a];
+            }
+        }
+    }
+    pcr_sync(ctx->stream);
+    release();
+    return rc;
+}
+
+extern "C" {
 
 int pcr_normals_hybrid(pcr_ctx* ctx, const pcr_cloud* cloud, double radius, int max_nn, int orient, const double viewpoint[3], double* normals_out) {
     if (!ctx || !cloud || !normals_out || !(radius > 0) || max_nn < 1 || max_nn > NB_CAP) return PCR_E_INVALID;

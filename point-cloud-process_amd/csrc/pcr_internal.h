@@ -109,6 +109,8 @@ struct pcr_ctx {
     size_t h_big_bytes = 0;
     void* h_stage = nullptr;              // pinned staging buffer for uploads from pageable caller memory (grown on demand, <= 64 MiB)
     size_t h_stage_bytes = 0;
+    void* h_init = nullptr;               // pinned packing block of the fused global initialisation (pcr_global_init_batch), grown on demand
+    size_t h_init_bytes = 0;
     void* h_down = nullptr;               // pinned double buffer for large device-to-host results (pcr_d2h_staged), 2 x h_down_half bytes
     size_t h_down_half = 0;
     size_t h_pinned_bytes = 0;
@@ -255,6 +257,16 @@ struct pcr_icp_loop_args {
 // whole ICP loop on the device (grid index); fills res like the host loop of pcr_icp
 // device -> pageable host memory through a pinned double buffer (large results: a pageable copy runs at ~4.5 GB/s)
 PCR_HIDDEN int pcr_d2h_staged(pcr_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+// Open3D's voxel_down_sample of every scan of a chunk at once (pcr_voxel.hip).  d_xyz: the chunk's points, 3 x f32 each, scan behind scan
+// (scans[s].first_pt .. + n_pts; mn / mx = the scan's bounding box).  Out, from the arena (the caller frees: sizes ng, ng, n_scans + 1):
+// the records by row WITHIN their scan, the scan of every record, the first record of every scan (+ the total) -- the latter also on the host.
+struct pcr_down_scan { unsigned int first_pt, n_pts; double mn[3], mx[3]; };
+// prepare_dataset + execute_global_registration for a share of pairs at once (pcr_fpfh.hip): scans[] = rows of clouds[] that a pair of todo[] uses;
+// T_init (16 doubles per row of pairs[]) gets the result of every pair with a valid hypothesis.  PCR_E_UNSUPPORTED: take the scans one by one.
+PCR_HIDDEN int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_clouds, const int64_t* scans, int64_t n_scans, const pcr_pair_ref* pairs,
+                                     const int64_t* todo, int64_t n_todo, const pcr_global_params* g, double* T_init, int host_threads);
+PCR_HIDDEN int pcr_voxel_downsample_scans(pcr_ctx* ctx, const float* d_xyz, int64_t n_pts, const pcr_down_scan* scans, int n_scans, double leaf, pcr_pt** down_out,
+                                          unsigned int** vsid_out, unsigned int** scan_first_out, unsigned int* scan_first_host, int64_t* ng_out);
 // small results (<= PCR_SMALL_D2H_BYTES) by a kernel writing into a pinned, device-mapped block: no copy engine (see pcr_core.hip).
 // pcr_d2h_small synchronises the stream; _enqueue only launches (mapped_host_dst must be device-mapped pinned memory of the context)
 constexpr size_t PCR_SMALL_D2H_BYTES = 16384;

@@ -490,6 +490,160 @@ static void voxel_release(pcr_ctx* ctx, voxel_work* w) {
     w->big_list = nullptr;
 }
 
+// ------------------------------------------------------------------------------------------------ many scans at once
+// Open3D's voxel_down_sample (mode 2 above) of EVERY scan of a chunk in one pass -- the pair loop's prepare_dataset
+// (Registration/main.py:33-36,197) preprocesses hundreds of scans of 20 000 - 120 000 points, and one scan at a time is a chain of
+// ~20 launches of a few microseconds each, several per pair.  The key of a point is (scan << LB) | voxel index within the scan's own
+// grid (same arithmetic as voxel_keys_kernel with the scan's own min bound and extents), ONE stable sort puts every scan's voxels
+// in the order the per-scan filter produces, and the emit kernels above run unchanged over all of them.
+struct down_scan_dev { unsigned int first_pt, n_pts; double mnx, mny, mnz, Dx, Dy; };
+
+__global__ void __launch_bounds__(256)
+scans_keys_kernel(const float* __restrict__ xyz, long long n, const down_scan_dev* __restrict__ scans, int n_scans, double leaf, int LB,
+                  unsigned long long* __restrict__ keys, unsigned int* __restrict__ vals) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = n_scans - 1;   // the scan that holds point i: the last one that starts at or before it
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long long)scans[mid].first_pt <= i) lo = mid;
+        else hi = mid - 1;
+    }
+    const down_scan_dev S = scans[lo];
+    const double px = (double)xyz[3 * i], py = (double)xyz[3 * i + 1], pz = (double)xyz[3 * i + 2];
+    const double hx = floor((px - S.mnx) / leaf);
+    const double hy = floor((py - S.mny) / leaf);
+    const double hz = floor((pz - S.mnz) / leaf);
+    const double h = (hx + hy * S.Dx) + (hz * S.Dx) * S.Dy;
+    keys[i] = ((unsigned long long)lo << LB) | (unsigned long long)h;
+    vals[i] = (unsigned int)i;
+}
+
+__global__ void __launch_bounds__(256)
+scans_gather_kernel(const float* __restrict__ xyz, const unsigned int* __restrict__ perm, long long n, vox_xyz* __restrict__ out, unsigned int* __restrict__ big_count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *big_count = 0u;
+    if (i >= n) return;
+    const size_t j = perm[i];
+    out[i] = vox_xyz{(double)xyz[3 * j], (double)xyz[3 * j + 1], (double)xyz[3 * j + 2]};
+}
+
+// first voxel of every scan and the scan of every voxel (a scan with points has voxels: every entry of scan_first is written)
+__global__ void __launch_bounds__(256)
+scans_first_kernel(const unsigned long long* __restrict__ keys_sorted, const unsigned int* __restrict__ heads, const unsigned int* __restrict__ ng_p, int LB, int n_scans,
+                   unsigned int* __restrict__ scan_first, unsigned int* __restrict__ vsid) {
+    const unsigned int ng = *ng_p;
+    for (unsigned int v = blockIdx.x * blockDim.x + threadIdx.x; v < ng; v += gridDim.x * blockDim.x) {
+        const unsigned int sid = (unsigned int)(keys_sorted[heads[v]] >> LB);
+        vsid[v] = sid;
+        if (v == 0 || (unsigned int)(keys_sorted[heads[v - 1]] >> LB) != sid) scan_first[sid] = v;
+        if (v == 0) scan_first[n_scans] = ng;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+scans_rows_kernel(pcr_pt* __restrict__ down, const unsigned int* __restrict__ vsid, const unsigned int* __restrict__ scan_first, const unsigned int* __restrict__ ng_p) {
+    const unsigned int ng = *ng_p;
+    for (unsigned int v = blockIdx.x * blockDim.x + threadIdx.x; v < ng; v += gridDim.x * blockDim.x)
+        down[v].id = (long long)(v - scan_first[vsid[v]]);   // the record's row within its own scan (what the per-scan filter writes)
+}
+
+int pcr_voxel_downsample_scans(pcr_ctx* ctx, const float* d_xyz, int64_t n_pts, const pcr_down_scan* scans, int n_scans, double leaf, pcr_pt** down_out,
+                               unsigned int** vsid_out, unsigned int** scan_first_out, unsigned int* scan_first_host, int64_t* ng_out) {
+    if (!ctx || !d_xyz || !scans || n_scans < 1 || n_pts < 1 || n_pts > 0x7fffffffll || !(leaf > 0) || !std::isfinite(leaf)) return PCR_E_INVALID;
+    if ((size_t)(n_scans + 1) * sizeof(unsigned int) > PCR_SMALL_D2H_BYTES) return PCR_E_UNSUPPORTED;
+    *down_out = nullptr; *vsid_out = nullptr; *scan_first_out = nullptr;
+    std::vector<down_scan_dev> h_sc((size_t)n_scans);
+    double bound = 1.0;
+    for (int s = 0; s < n_scans; ++s) {
+        down_scan_dev& d = h_sc[(size_t)s];
+        d.first_pt = scans[s].first_pt; d.n_pts = scans[s].n_pts;
+        double mn[3], D[3];
+        for (int k = 0; k < 3; ++k) {   // (Open3D's binning, as voxel_prepare does it)
+            mn[k] = scans[s].mn[k] - leaf * 0.5;
+            D[k] = floor((scans[s].mx[k] - mn[k]) / leaf) + 1.0;
+        }
+        const double b = D[0] * D[1] * D[2];
+        if (!(b >= 1.0 && b < 1099511627776.0)) return PCR_E_UNSUPPORTED;   // 2^40 (also NaN / inf): such a scan goes through the per-scan path
+        if (b > bound) bound = b;
+        d.mnx = mn[0]; d.mny = mn[1]; d.mnz = mn[2]; d.Dx = D[0]; d.Dy = D[1];
+    }
+    int LB = 1;
+    while (((unsigned long long)bound >> LB) != 0ull) ++LB;
+    int SB = 1;
+    while (((unsigned long long)(n_scans - 1) >> SB) != 0ull) ++SB;
+    const int end_bit = LB + SB;
+    const long long n = n_pts;
+    const int grid_n = (int)((n + 255) / 256);
+    pcr_dev_block b_sc(ctx), b_keys(ctx), b_keys2(ctx), b_vals(ctx), b_perm(ctx), b_xyz(ctx), b_heads(ctx), b_big(ctx), b_temp(ctx), b_temp2(ctx), b_full(ctx);
+    int rc;
+    if ((rc = b_sc.alloc(sizeof(down_scan_dev) * n_scans)) || (rc = b_keys.alloc(8 * (size_t)n)) || (rc = b_keys2.alloc(8 * (size_t)n)) || (rc = b_vals.alloc(4 * (size_t)n)) ||
+        (rc = b_perm.alloc(4 * (size_t)n)) || (rc = b_xyz.alloc(sizeof(vox_xyz) * (size_t)n)) || (rc = b_heads.alloc(4 * (size_t)(n + 1))) ||
+        (rc = b_big.alloc(4 * (size_t)(n / 65 + 1))))
+        return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(b_sc.p, h_sc.data(), sizeof(down_scan_dev) * n_scans, hipMemcpyHostToDevice, ctx->stream));
+    unsigned long long *d_keys = b_keys.as<unsigned long long>(), *d_keys2 = b_keys2.as<unsigned long long>();
+    hipLaunchKernelGGL(scans_keys_kernel, dim3(grid_n), dim3(256), 0, ctx->stream, d_xyz, n, (const down_scan_dev*)b_sc.as<down_scan_dev>(), n_scans, leaf, LB, d_keys,
+                       b_vals.as<unsigned int>());
+    size_t temp_bytes = 0, temp2 = 0;
+    PCR_HIP(ctx, pcr_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, b_vals.as<unsigned int>(), b_perm.as<unsigned int>(), (size_t)n, (unsigned int)end_bit, ctx->stream));
+    if ((rc = b_temp.alloc(temp_bytes))) return rc;
+    PCR_HIP(ctx, pcr_sort_pairs(b_temp.p, temp_bytes, d_keys, d_keys2, b_vals.as<unsigned int>(), b_perm.as<unsigned int>(), (size_t)n, (unsigned int)end_bit, ctx->stream));
+    unsigned int* const big_count = ctx->d_counters + 49;
+    unsigned int* const n_groups = ctx->d_counters + 48;
+    hipLaunchKernelGGL(scans_gather_kernel, dim3(grid_n), dim3(256), 0, ctx->stream, d_xyz, (const unsigned int*)b_perm.as<unsigned int>(), n, b_xyz.as<vox_xyz>(), big_count);
+    const head_flag<unsigned long long> flag_op{d_keys2};
+    auto positions = rocprim::counting_iterator<unsigned int>(0u);
+    auto flags = rocprim::make_transform_iterator(positions, flag_op);
+    PCR_HIP(ctx, rocprim::select(nullptr, temp2, positions, flags, b_heads.as<unsigned int>(), n_groups, (size_t)n, ctx->stream));
+    if ((rc = b_temp2.alloc(temp2))) return rc;
+    PCR_HIP(ctx, rocprim::select(b_temp2.p, temp2, positions, flags, b_heads.as<unsigned int>(), n_groups, (size_t)n, ctx->stream));
+    // every voxel of the chunk (the count is only known on the device: the emit kernels stride over it), written into a buffer of the
+    // upper bound first
+    if ((rc = b_full.alloc(sizeof(pcr_pt) * (size_t)n))) return rc;
+    pcr_pt* const d_full = b_full.as<pcr_pt>();
+    {
+        long long blocks = (n * 8 + 255) / 256;
+        if (blocks > 16ll * ctx->cu_count) blocks = 16ll * ctx->cu_count;
+        hipLaunchKernelGGL(voxel_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const vox_xyz*)b_xyz.as<vox_xyz>(), (const unsigned int*)b_heads.as<unsigned int>(),
+                           (const unsigned int*)n_groups, n, 2, 0ull, d_full, (double*)nullptr, big_count, b_big.as<unsigned int>());
+        long long big_max = (n / (voxel_big_threshold(2) + 1) + 1 + 3) / 4;
+        if (big_max > 8ll * ctx->cu_count) big_max = 8ll * ctx->cu_count;
+        hipLaunchKernelGGL(voxel_emit_big_kernel, dim3((unsigned)big_max), dim3(256), 0, ctx->stream, (const vox_xyz*)b_xyz.as<vox_xyz>(),
+                           (const unsigned int*)b_heads.as<unsigned int>(), (const unsigned int*)n_groups, n, 2, d_full, (double*)nullptr, (const unsigned int*)big_count,
+                           (const unsigned int*)b_big.as<unsigned int>());
+    }
+    unsigned int *d_first = nullptr, *d_vsid = nullptr;
+    if ((rc = pcr_dev_alloc(ctx, 4 * (size_t)(n_scans + 1), (void**)&d_first))) return rc;
+    // (the voxel count is at most the point count; the scan-of-voxel list is cut to size below)
+    pcr_dev_block b_vsid(ctx);
+    if ((rc = b_vsid.alloc(4 * (size_t)n))) { pcr_dev_free(ctx, d_first, 4 * (size_t)(n_scans + 1)); return rc; }
+    const unsigned sgrid = (unsigned)(grid_n < 4 * ctx->cu_count ? grid_n : 4 * ctx->cu_count);
+    hipLaunchKernelGGL(scans_first_kernel, dim3(sgrid), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys2, (const unsigned int*)b_heads.as<unsigned int>(),
+                       (const unsigned int*)n_groups, LB, n_scans, d_first, b_vsid.as<unsigned int>());
+    hipLaunchKernelGGL(scans_rows_kernel, dim3(sgrid), dim3(256), 0, ctx->stream, d_full, (const unsigned int*)b_vsid.as<unsigned int>(), (const unsigned int*)d_first,
+                       (const unsigned int*)n_groups);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) rc = pcr_d2h_small(ctx, scan_first_host, d_first, 4 * (size_t)(n_scans + 1));   // (synchronises)
+    if (e != hipSuccess || rc) {
+        pcr_dev_free(ctx, d_first, 4 * (size_t)(n_scans + 1));
+        if (e != hipSuccess) { ctx->last_error = std::string("voxel filter (scans): ") + hipGetErrorString(e); return PCR_E_HIP; }
+        return rc;
+    }
+    const int64_t ng = (int64_t)scan_first_host[n_scans];
+    // cut to size
+    pcr_pt* d_down = nullptr;
+    if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * (size_t)(ng > 0 ? ng : 1), (void**)&d_down)) || (rc = pcr_dev_alloc(ctx, 4 * (size_t)(ng > 0 ? ng : 1), (void**)&d_vsid))) {
+        if (d_down) pcr_dev_free(ctx, d_down, sizeof(pcr_pt) * (size_t)(ng > 0 ? ng : 1));
+        pcr_dev_free(ctx, d_first, 4 * (size_t)(n_scans + 1));
+        return rc;
+    }
+    PCR_HIP(ctx, hipMemcpyAsync(d_down, d_full, sizeof(pcr_pt) * (size_t)ng, hipMemcpyDeviceToDevice, ctx->stream));
+    PCR_HIP(ctx, hipMemcpyAsync(d_vsid, b_vsid.p, 4 * (size_t)ng, hipMemcpyDeviceToDevice, ctx->stream));
+    *down_out = d_down; *vsid_out = d_vsid; *scan_first_out = d_first; *ng_out = ng;
+    return PCR_OK;
+}
+
 extern "C" {
 
 int pcr_voxel_keys(pcr_ctx* ctx, const double* xyz, int64_t n, double leaf, double* h_out, double D_out[3]) {

@@ -1,0 +1,39 @@
+"""The fused global initialisation (pcr_global_init_batch: every scan of a share down-sampled by one sort, every later stage one launch)
+against the scans one by one (PCR_INIT_PER_SCAN=1): initial transforms and registration results must be the same bits.  Runs itself
+twice (the switch is read once per process).  PAIRS pairs of POINTS-point scans, half of them sharing scans with a neighbour pair."""
+import importlib, os, subprocess, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+P = int(os.environ.get("PAIRS", 24)); N = int(os.environ.get("POINTS", 20000))
+if len(sys.argv) > 1:
+    pkg = importlib.import_module("point-cloud-process_amd")
+    batch = importlib.import_module("point-cloud-process_amd.batch")
+    pairs, prev = [], None
+    for i in range(P):
+        s, t, _ = pkg.synthetic.perturbed_pair(N + 137 * (i % 5), seed=3000 + i, angle_deg=20.0 + (i % 7), t=(2.0 + 0.1 * (i % 5), -1.0, 0.05))
+        if i % 2 == 1 and prev is not None:
+            s = prev                      # a chain: this pair's source is the last pair's target (one scan, two pairs)
+        pairs.append((s, t, None))
+        prev = t
+    pairs.append((pairs[0][0][:1], pairs[0][1], None))       # a one-point scan
+    out = batch.native_register_share(pairs, device=0, streams=8, global_init=True, return_init=True)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); out = batch.native_register_share(pairs, device=0, streams=8, global_init=True, return_init=True); best = min(best, time.perf_counter() - t0)
+    np.savez(sys.argv[1], T_init=np.asarray([r["T_init"] for r in out]), T=np.asarray([r["T"] for r in out]), iters=np.asarray([r["iters"] for r in out]), ms=best * 1e3)
+    sys.exit(0)
+outs = []
+for tag, env in (("fused", {}), ("per_scan", {"PCR_INIT_PER_SCAN": "1"})):
+    f = f"/tmp/init_{tag}.npz"
+    e = dict(os.environ); e.update(env)
+    subprocess.run([sys.executable, os.path.abspath(__file__), f], check=True, env=e)
+    outs.append(np.load(f))
+a, b = outs
+moved = int(np.sum(np.any(a["T_init"].reshape(len(a["T_init"]), -1) != np.eye(4).reshape(-1), axis=1)))
+print(f"{P + 1} pairs x {N} points: fused {float(a['ms']):.2f} ms, scan by scan {float(b['ms']):.2f} ms; pairs with a hypothesis {moved}; "
+      f"T_init equal {np.array_equal(a['T_init'], b['T_init'])}, T equal {np.array_equal(a['T'], b['T'])}, iterations equal {np.array_equal(a['iters'], b['iters'])}")
+if not (np.array_equal(a["T_init"], b["T_init"]) and np.array_equal(a["T"], b["T"])):
+    d = np.abs(a["T_init"] - b["T_init"]).reshape(len(a["T_init"]), -1).max(axis=1)
+    print("   rows that differ:", np.nonzero(d)[0].tolist()[:20], "max abs", d.max())
+    sys.exit(1)
