@@ -1054,8 +1054,7 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
     if (!(g->voxel_size > 0) || !(g->normal_radius > 0) || !(g->fpfh_radius > 0) || g->normal_max_nn < 1 || g->normal_max_nn > NB_CAP || g->fpfh_max_nn < 2 ||
         g->fpfh_max_nn > NB_CAP || g->ransac.max_iteration < 1 || !(g->ransac.max_distance > 0))
         return PCR_E_INVALID;
-    static const bool off = getenv("PCR_INIT_PER_SCAN") != nullptr;   // A/B: always the scans one by one
-    if (off) return PCR_E_UNSUPPORTED;
+    if (getenv("PCR_INIT_PER_SCAN") != nullptr) return PCR_E_UNSUPPORTED;   // A/B and tests: the scans one by one (read per call)
     hipSetDevice(ctx->device);
     static const bool timing = getenv("PCR_INIT_TIMING") != nullptr;   // diagnostics: milliseconds per stage to stderr (synchronises after every stage)
     auto t_last = std::chrono::steady_clock::now();
