@@ -40,11 +40,16 @@ __device__ static inline bool nb_less(const nb_entry& a, const nb_entry& b) { re
 // The 27 cells are looked up by 27 lanes AT ONCE (one lane walking them one after the other paid 27 dependent round trips per
 // point), the non-empty ones become a flat list of ranges (cell_s / cell_o: start and exclusive point offset) and the 64 lanes
 // stride over the concatenation, so a scan is ceil(points / 64) round trips whatever the cells' sizes.
-struct hybrid_lds {
-    nb_entry nb[NB_CAP];
+// CAP < NB_CAP: a block with a small candidate array (more blocks per CU); a sphere that holds more returns -2 and the point is done
+// again by the block with the full array.
+template <int CAP>
+struct hybrid_lds_t {
+    nb_entry nb[CAP];
     unsigned int cell_s[28], cell_o[28];
 };
-__device__ static int gather_hybrid(const pcr_grid_view& gv, double qx, double qy, double qz, double r2, int max_nn, hybrid_lds* L) {
+typedef hybrid_lds_t<NB_CAP> hybrid_lds;
+template <int CAP>
+__device__ static int gather_hybrid(const pcr_grid_view& gv, double qx, double qy, double qz, double r2, int max_nn, hybrid_lds_t<CAP>* L) {
     nb_entry* const nb = L->nb;
     const int lane = threadIdx.x;
     bool clamped = false;
@@ -101,12 +106,13 @@ __device__ static int gather_hybrid(const pcr_grid_view& gv, double qx, double q
             }
             const unsigned long long m = __ballot(keep);
             const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            if (store && keep && found + rank < NB_CAP) nb[found + rank] = en;
+            if (store && keep && found + rank < CAP) nb[found + rank] = en;
             found += __popcll(m);
         }
         return found;
     };
     int cnt = scan(r2, true);
+    if (CAP < NB_CAP && cnt > CAP) return -2;
     if (cnt > NB_CAP) {
         unsigned long long lo = 0, hi = (unsigned long long)__double_as_longlong(r2);
         bool found = false;
@@ -191,11 +197,14 @@ __device__ static void smallest_eigvec(const double S[6], double n[3]) {
 }
 
 // ------------------------------------------------------------ hybrid normals
-__device__ static void normals_body(const pcr_grid_view& gv, const pcr_pt& p, double r2, int max_nn, int orient, double vx, double vy, double vz,
-                                    double* __restrict__ normals /* (n,3) by row */, int* __restrict__ fail, hybrid_lds* L) {
+// returns false when the point has to be done again with the full candidate array
+template <int CAP>
+__device__ static bool normals_body(const pcr_grid_view& gv, const pcr_pt& p, double r2, int max_nn, int orient, double vx, double vy, double vz,
+                                    double* __restrict__ normals /* (n,3) by row */, int* __restrict__ fail, hybrid_lds_t<CAP>* L) {
     nb_entry* const nb = L->nb;
-    const int cnt = gather_hybrid(gv, p.x, p.y, p.z, r2, max_nn, L);
-    if (cnt < 0) { if (threadIdx.x == 0) atomicAdd(fail, 1); return; }
+    const int cnt = gather_hybrid<CAP>(gv, p.x, p.y, p.z, r2, max_nn, L);
+    if (cnt == -2) return false;
+    if (cnt < 0) { if (threadIdx.x == 0) atomicAdd(fail, 1); return true; }
     double nrm[3] = {0.0, 0.0, 1.0};  // Open3D's value for neighbourhoods of fewer than 3 points
     if (cnt >= 3) {
         // cumulants about the query point (Open3D accumulates raw coordinates; centring first is the same
@@ -220,6 +229,7 @@ __device__ static void normals_body(const pcr_grid_view& gv, const pcr_pt& p, do
     }
     const double n0 = nrm[0], n1 = nrm[1], n2 = nrm[2];
     if (threadIdx.x < 3) normals[3 * p.id + threadIdx.x] = threadIdx.x == 0 ? n0 : (threadIdx.x == 1 ? n1 : n2);
+    return true;
 }
 
 __global__ void __launch_bounds__(64) hybrid_normals_kernel(pcr_grid_view gv, long long n, double r2, int max_nn, int orient, double vx, double vy,
@@ -228,7 +238,7 @@ __global__ void __launch_bounds__(64) hybrid_normals_kernel(pcr_grid_view gv, lo
     const long long i = blockIdx.x;
     if (i >= n) return;
     const pcr_pt p = gv.pts[i];
-    normals_body(gv, p, r2, max_nn, orient, vx, vy, vz, normals, fail, &s_L);
+    normals_body<NB_CAP>(gv, p, r2, max_nn, orient, vx, vy, vz, normals, fail, &s_L);
 }
 
 // The down-sampled scans of a chunk, one behind the other (pcr_voxel_downsample_scans): record v belongs to scan vsid[v], whose records
@@ -247,14 +257,24 @@ __device__ static inline unsigned int scans_block_view(const scans_view& V, long
     gv->cell0 = 1.0; gv->inv_cell0 = 1.0;
     return base;
 }
-__global__ void __launch_bounds__(64) normals_scans_kernel(scans_view V, long long ng, double r2, int max_nn, double* __restrict__ normals /* (ng,3) */, int* __restrict__ fail) {
-    __shared__ hybrid_lds s_L;
-    const long long i = blockIdx.x;
-    if (i >= ng) return;
-    pcr_grid_view gv;
-    const unsigned int base = scans_block_view(V, i, &gv);
-    const pcr_pt p = V.down[i];
-    normals_body(gv, p, r2, max_nn, 1, 0.0, 0.0, 0.0, normals + 3 * (size_t)base, fail, &s_L);
+// Two launches per stage: every point with a SMALL candidate array (16 blocks and more per CU instead of 9: a block is a chain of round
+// trips and LDS sorts, its throughput is how many run side by side), then the few whose sphere holds more, from the list the first left
+// (`todo` / `todo_count`; a fixed grid strides over it -- its length is only known on the device).
+template <int CAP>
+__global__ void __launch_bounds__(64) normals_scans_kernel(scans_view V, long long ng, double r2, int max_nn, double* __restrict__ normals /* (ng,3) */, int* __restrict__ fail,
+                                                           const unsigned int* __restrict__ todo, const unsigned int* __restrict__ todo_count, unsigned int* __restrict__ redo,
+                                                           unsigned int* __restrict__ redo_count) {
+    __shared__ hybrid_lds_t<CAP> s_L;
+    const long long n_do = todo ? (long long)*todo_count : ng;
+    for (long long t = blockIdx.x; t < n_do; t += gridDim.x) {
+        const long long i = todo ? (long long)todo[t] : t;
+        pcr_grid_view gv;
+        const unsigned int base = scans_block_view(V, i, &gv);
+        const pcr_pt p = V.down[i];
+        const bool done = normals_body<CAP>(gv, p, r2, max_nn, 1, 0.0, 0.0, 0.0, normals + 3 * (size_t)base, fail, &s_L);
+        if (!done && threadIdx.x == 0) redo[atomicAdd(redo_count, 1u)] = (unsigned int)i;
+        __syncthreads();   // (the candidate array is reused by the next point)
+    }
 }
 
 // ---------------------------------------------------------------------- SPFH
@@ -292,13 +312,15 @@ __device__ static inline int clamp_bin(double x) {
     return h < 0 ? 0 : (h > 10 ? 10 : h);
 }
 
-__device__ static void spfh_body(const pcr_grid_view& gv, const pcr_pt& p, double r2, int max_nn, const double* __restrict__ normals /* by row */,
+template <int CAP>
+__device__ static bool spfh_body(const pcr_grid_view& gv, const pcr_pt& p, double r2, int max_nn, const double* __restrict__ normals /* by row */,
                                  double* __restrict__ spfh /* (n,33) by row */, unsigned int* __restrict__ nb_id /* (n,max_nn) by row */, double* __restrict__ nb_d2,
-                                 int* __restrict__ nb_cnt, int* __restrict__ fail, hybrid_lds* L, int* hist /* LDS, 33 */) {
+                                 int* __restrict__ nb_cnt, int* __restrict__ fail, hybrid_lds_t<CAP>* L, int* hist /* LDS, 33 */) {
     nb_entry* const nb = L->nb;
     if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-    const int cnt = gather_hybrid(gv, p.x, p.y, p.z, r2, max_nn, L);  // ends with a barrier
-    if (cnt < 0) { if (threadIdx.x == 0) atomicAdd(fail, 1); return; }
+    const int cnt = gather_hybrid<CAP>(gv, p.x, p.y, p.z, r2, max_nn, L);  // ends with a barrier
+    if (cnt == -2) return false;
+    if (cnt < 0) { if (threadIdx.x == 0) atomicAdd(fail, 1); return true; }
     const double p1[3] = {p.x, p.y, p.z};
     const double n1[3] = {normals[3 * p.id], normals[3 * p.id + 1], normals[3 * p.id + 2]};
     for (int k = threadIdx.x; k < cnt; k += 64) {
@@ -325,6 +347,7 @@ __device__ static void spfh_body(const pcr_grid_view& gv, const pcr_pt& p, doubl
         }
         spfh[33 * (long long)p.id + threadIdx.x] = v;
     }
+    return true;
 }
 
 __global__ void __launch_bounds__(64)
@@ -335,20 +358,27 @@ spfh_kernel(pcr_grid_view gv, long long n, double r2, int max_nn, const double* 
     const long long i = blockIdx.x;
     if (i >= n) return;
     const pcr_pt p = gv.pts[i];
-    spfh_body(gv, p, r2, max_nn, normals, spfh, nb_id, nb_d2, nb_cnt, fail, &s_L, hist);
+    spfh_body<NB_CAP>(gv, p, r2, max_nn, normals, spfh, nb_id, nb_d2, nb_cnt, fail, &s_L, hist);
 }
 
+template <int CAP>
 __global__ void __launch_bounds__(64)
 spfh_scans_kernel(scans_view V, long long ng, double r2, int max_nn, const double* __restrict__ normals, double* __restrict__ spfh, unsigned int* __restrict__ nb_id,
-                  double* __restrict__ nb_d2, int* __restrict__ nb_cnt, int* __restrict__ fail) {
-    __shared__ hybrid_lds s_L;
+                  double* __restrict__ nb_d2, int* __restrict__ nb_cnt, int* __restrict__ fail, const unsigned int* __restrict__ todo,
+                  const unsigned int* __restrict__ todo_count, unsigned int* __restrict__ redo, unsigned int* __restrict__ redo_count) {
+    __shared__ hybrid_lds_t<CAP> s_L;
     __shared__ int hist[33];
-    const long long i = blockIdx.x;
-    if (i >= ng) return;
-    pcr_grid_view gv;
-    const size_t base = scans_block_view(V, i, &gv);
-    const pcr_pt p = V.down[i];
-    spfh_body(gv, p, r2, max_nn, normals + 3 * base, spfh + 33 * base, nb_id + base * (size_t)max_nn, nb_d2 + base * (size_t)max_nn, nb_cnt + base, fail, &s_L, hist);
+    const long long n_do = todo ? (long long)*todo_count : ng;
+    for (long long t = blockIdx.x; t < n_do; t += gridDim.x) {
+        const long long i = todo ? (long long)todo[t] : t;
+        pcr_grid_view gv;
+        const size_t base = scans_block_view(V, i, &gv);
+        const pcr_pt p = V.down[i];
+        const bool done = spfh_body<CAP>(gv, p, r2, max_nn, normals + 3 * base, spfh + 33 * base, nb_id + base * (size_t)max_nn, nb_d2 + base * (size_t)max_nn, nb_cnt + base,
+                                         fail, &s_L, hist);
+        if (!done && threadIdx.x == 0) redo[atomicAdd(redo_count, 1u)] = (unsigned int)i;
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------- FPFH
@@ -404,11 +434,12 @@ fpfh_kernel(long long n, int max_nn, const double* __restrict__ spfh, const unsi
 }
 
 // (the records of a scan sit in row order: record base + r is row r)
+template <int CAP>   // >= max_nn (a list never holds more)
 __global__ void __launch_bounds__(64)
 fpfh_scans_kernel(scans_view V, long long ng, int max_nn, const double* __restrict__ spfh, const unsigned int* __restrict__ nb_id, const double* __restrict__ nb_d2,
                   const int* __restrict__ nb_cnt, double* __restrict__ fpfh) {
-    __shared__ unsigned int s_id[NB_CAP];
-    __shared__ double s_d2[NB_CAP];
+    __shared__ unsigned int s_id[CAP];
+    __shared__ double s_d2[CAP];
     __shared__ double s_acc[33];
     const long long i = blockIdx.x;
     if (i >= ng) return;
@@ -513,86 +544,106 @@ __host__ __device__ static inline unsigned long long mix64(unsigned long long x)
     return x ^ (x >> 31);
 }
 
-// one wave per hypothesis; out: inl[h] (-1 = rejected by a checker), err2[h], T[h][12]
+// out: inl[h] (-1 = rejected by a checker), err2[h], T[h][12]
+// 64 hypotheses per wave: every LANE draws its own sample and runs the checkers and the Kabsch step on it (the same scalar code the whole
+// wave used to run 64 times over for one hypothesis); the few that pass are then scored one after the other by all 64 lanes together.
+// Same arithmetic per hypothesis as ever: the batch's results do not depend on how hypotheses are dealt to waves.
 __device__ static void ransac_eval(const ransac_args& a, const ransac_state* __restrict__ st, int* __restrict__ inl, double* __restrict__ err2,
-                                   double* __restrict__ Tout, const int h) {
-    if (h >= a.n_iter || st->stop) return;
+                                   double* __restrict__ Tout, const int h_base) {
+    if (h_base >= a.n_iter || st->stop) return;
+    const int lane = threadIdx.x;
+    const int h = h_base + lane;
     const int m = st->m;
     const unsigned long long itr = (unsigned long long)(a.first_iter + h);
-    if ((long long)itr >= st->exit_itr) return;   // (the walk never looks at it)
-    double s[3][3], t[3][3];
-    for (int j = 0; j < 3; ++j) {
-        const unsigned int c = (unsigned int)(mix64(a.seed ^ mix64(itr * 3 + j)) % (unsigned long long)m);
-        const pcr_pt ps = a.src[a.corr[2 * c]], pt = a.tgt[a.corr[2 * c + 1]];
-        s[j][0] = ps.x; s[j][1] = ps.y; s[j][2] = ps.z;
-        t[j][0] = pt.x; t[j][1] = pt.y; t[j][2] = pt.z;
-    }
-    bool ok = true;
-    if (a.edge_sim > 0) {
-        for (int i = 0; i < 3 && ok; ++i)
-            for (int j = i + 1; j < 3; ++j) {
-                const double ds = sqrt(((s[i][0] - s[j][0]) * (s[i][0] - s[j][0]) + (s[i][1] - s[j][1]) * (s[i][1] - s[j][1])) + (s[i][2] - s[j][2]) * (s[i][2] - s[j][2]));
-                const double dt = sqrt(((t[i][0] - t[j][0]) * (t[i][0] - t[j][0]) + (t[i][1] - t[j][1]) * (t[i][1] - t[j][1])) + (t[i][2] - t[j][2]) * (t[i][2] - t[j][2]));
-                if (ds < dt * a.edge_sim || dt < ds * a.edge_sim) { ok = false; break; }
-            }
-    }
+    // (a hypothesis at or behind exit_itr is never looked at by the walk)
+    const bool mine = h < a.n_iter && (long long)itr < st->exit_itr;
+    bool ok = mine;
     double R[9], tr[3];
-    if (ok) {
-        // Kabsch on the three pairs (procrustes_transformation, icp_template.py:43-54; proper rotation for the rank-2 case)
-        double mo[18];
-        for (int k = 0; k < 18; ++k) mo[k] = 0.0;
-        const double org[3] = {s[0][0], s[0][1], s[0][2]};
-        mo[0] = 3.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = 0.0;
+    tr[0] = tr[1] = tr[2] = 0.0;
+    if (mine) {
+        double s[3][3], t[3][3];
         for (int j = 0; j < 3; ++j) {
-            const double ax = s[j][0] - org[0], ay = s[j][1] - org[1], az = s[j][2] - org[2];
-            const double bx = t[j][0] - org[0], by = t[j][1] - org[1], bz = t[j][2] - org[2];
-            mo[1] += ax; mo[2] += ay; mo[3] += az;
-            mo[4] += bx; mo[5] += by; mo[6] += bz;
-            mo[7] += bx * ax; mo[8] += bx * ay; mo[9] += bx * az;
-            mo[10] += by * ax; mo[11] += by * ay; mo[12] += by * az;
-            mo[13] += bz * ax; mo[14] += bz * ay; mo[15] += bz * az;
-            mo[16] += (ax * ax + ay * ay) + az * az;
-            mo[17] += (bx * bx + by * by) + bz * bz;
+            const unsigned int c = (unsigned int)(mix64(a.seed ^ mix64(itr * 3 + j)) % (unsigned long long)m);
+            const pcr_pt ps = a.src[a.corr[2 * c]], pt = a.tgt[a.corr[2 * c + 1]];
+            s[j][0] = ps.x; s[j][1] = ps.y; s[j][2] = ps.z;
+            t[j][0] = pt.x; t[j][1] = pt.y; t[j][2] = pt.z;
         }
-        pcr::kabsch_from_moments(mo, org, R, tr, nullptr);
-        for (int k = 0; k < 9; ++k) ok = ok && (R[k] == R[k]);
-        if (ok && a.check_distance) {
+        if (a.edge_sim > 0) {
+            for (int i = 0; i < 3 && ok; ++i)
+                for (int j = i + 1; j < 3; ++j) {
+                    const double ds = sqrt(((s[i][0] - s[j][0]) * (s[i][0] - s[j][0]) + (s[i][1] - s[j][1]) * (s[i][1] - s[j][1])) + (s[i][2] - s[j][2]) * (s[i][2] - s[j][2]));
+                    const double dt = sqrt(((t[i][0] - t[j][0]) * (t[i][0] - t[j][0]) + (t[i][1] - t[j][1]) * (t[i][1] - t[j][1])) + (t[i][2] - t[j][2]) * (t[i][2] - t[j][2]));
+                    if (ds < dt * a.edge_sim || dt < ds * a.edge_sim) { ok = false; break; }
+                }
+        }
+        if (ok) {
+            // Kabsch on the three pairs (procrustes_transformation, icp_template.py:43-54; proper rotation for the rank-2 case)
+            double mo[18];
+            for (int k = 0; k < 18; ++k) mo[k] = 0.0;
+            const double org[3] = {s[0][0], s[0][1], s[0][2]};
+            mo[0] = 3.0;
             for (int j = 0; j < 3; ++j) {
-                const double x = ((R[0] * s[j][0] + R[1] * s[j][1]) + R[2] * s[j][2]) + tr[0] - t[j][0];
-                const double y = ((R[3] * s[j][0] + R[4] * s[j][1]) + R[5] * s[j][2]) + tr[1] - t[j][1];
-                const double z = ((R[6] * s[j][0] + R[7] * s[j][1]) + R[8] * s[j][2]) + tr[2] - t[j][2];
-                if (sqrt((x * x + y * y) + z * z) > a.max_dist) ok = false;
+                const double ax = s[j][0] - org[0], ay = s[j][1] - org[1], az = s[j][2] - org[2];
+                const double bx = t[j][0] - org[0], by = t[j][1] - org[1], bz = t[j][2] - org[2];
+                mo[1] += ax; mo[2] += ay; mo[3] += az;
+                mo[4] += bx; mo[5] += by; mo[6] += bz;
+                mo[7] += bx * ax; mo[8] += bx * ay; mo[9] += bx * az;
+                mo[10] += by * ax; mo[11] += by * ay; mo[12] += by * az;
+                mo[13] += bz * ax; mo[14] += bz * ay; mo[15] += bz * az;
+                mo[16] += (ax * ax + ay * ay) + az * az;
+                mo[17] += (bx * bx + by * by) + bz * bz;
+            }
+            pcr::kabsch_from_moments(mo, org, R, tr, nullptr);
+            for (int k = 0; k < 9; ++k) ok = ok && (R[k] == R[k]);
+            if (ok && a.check_distance) {
+                for (int j = 0; j < 3; ++j) {
+                    const double x = ((R[0] * s[j][0] + R[1] * s[j][1]) + R[2] * s[j][2]) + tr[0] - t[j][0];
+                    const double y = ((R[3] * s[j][0] + R[4] * s[j][1]) + R[5] * s[j][2]) + tr[1] - t[j][1];
+                    const double z = ((R[6] * s[j][0] + R[7] * s[j][1]) + R[8] * s[j][2]) + tr[2] - t[j][2];
+                    if (sqrt((x * x + y * y) + z * z) > a.max_dist) ok = false;
+                }
             }
         }
+        if (!ok) { inl[h] = -1; err2[h] = 0.0; }
     }
-    if (!ok) {
-        if (threadIdx.x == 0) { inl[h] = -1; err2[h] = 0.0; }
-        return;
-    }
-    int good = 0;
-    double e2 = 0.0;
-    for (int c = threadIdx.x; c < m; c += 64) {
-        const pcr_pt ps = a.src[a.corr[2 * c]], pt = a.tgt[a.corr[2 * c + 1]];
-        const double x = ((R[0] * ps.x + R[1] * ps.y) + R[2] * ps.z) + tr[0] - pt.x;
-        const double y = ((R[3] * ps.x + R[4] * ps.y) + R[5] * ps.z) + tr[1] - pt.y;
-        const double z = ((R[6] * ps.x + R[7] * ps.y) + R[8] * ps.z) + tr[2] - pt.z;
-        const double dis = sqrt((x * x + y * y) + z * z);
-        if (dis < a.max_dist) { ++good; e2 += dis * dis; }
-    }
-    e2 = wave_sum(e2);
+    // ---- the survivors, one after the other, scored by the whole wave
+    unsigned long long mk = __ballot(ok);
+    while (mk) {
+        const int l = (int)__ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        double Rl[9], tl[3];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) good += __shfl_xor(good, off, 64);
-    if (threadIdx.x == 0) {
-        inl[h] = good;
-        err2[h] = e2;
-        for (int k = 0; k < 9; ++k) Tout[12 * (long long)h + k] = R[k];
-        for (int k = 0; k < 3; ++k) Tout[12 * (long long)h + 9 + k] = tr[k];
+        for (int k = 0; k < 9; ++k) Rl[k] = __shfl(R[k], l, 64);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tl[k] = __shfl(tr[k], l, 64);
+        int good = 0;
+        double e2 = 0.0;
+        for (int c = lane; c < m; c += 64) {
+            const pcr_pt ps = a.src[a.corr[2 * c]], pt = a.tgt[a.corr[2 * c + 1]];
+            const double x = ((Rl[0] * ps.x + Rl[1] * ps.y) + Rl[2] * ps.z) + tl[0] - pt.x;
+            const double y = ((Rl[3] * ps.x + Rl[4] * ps.y) + Rl[5] * ps.z) + tl[1] - pt.y;
+            const double z = ((Rl[6] * ps.x + Rl[7] * ps.y) + Rl[8] * ps.z) + tl[2] - pt.z;
+            const double dis = sqrt((x * x + y * y) + z * z);
+            if (dis < a.max_dist) { ++good; e2 += dis * dis; }
+        }
+        e2 = wave_sum(e2);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) good += __shfl_xor(good, off, 64);
+        if (lane == 0) {
+            const int hl = h_base + l;
+            inl[hl] = good;
+            err2[hl] = e2;
+            for (int k = 0; k < 9; ++k) Tout[12 * (long long)hl + k] = Rl[k];
+            for (int k = 0; k < 3; ++k) Tout[12 * (long long)hl + 9 + k] = tl[k];
+        }
     }
 }
 
 __global__ void __launch_bounds__(64) ransac_kernel(ransac_args a, const ransac_state* __restrict__ st, int* __restrict__ inl, double* __restrict__ err2,
                                                     double* __restrict__ Tout) {
-    ransac_eval(a, st, inl, err2, Tout, (int)blockIdx.x);
+    ransac_eval(a, st, inl, err2, Tout, 64 * (int)blockIdx.x);
 }
 
 // ONE wave: the sequential loop over the batch -- iteration order, running best (IsBetterRANSACThan: higher fitness, or equal
@@ -763,7 +814,7 @@ __device__ static inline ransac_args job_args(const init_job& J, const ransac_co
 __global__ void __launch_bounds__(64) ransac_jobs_kernel(const init_job* __restrict__ jobs, const int* __restrict__ active, ransac_common c) {
     const init_job J = jobs[active ? active[blockIdx.y] : blockIdx.y];
     const ransac_args a = job_args(J, c);
-    ransac_eval(a, J.st, J.inl, J.err2, J.Tout, (int)blockIdx.x);
+    ransac_eval(a, J.st, J.inl, J.err2, J.Tout, 64 * (int)blockIdx.x);
 }
 __global__ void __launch_bounds__(64) ransac_walk_jobs_kernel(const init_job* __restrict__ jobs, const int* __restrict__ active, ransac_common c) {
     const init_job J = jobs[active ? active[blockIdx.x] : blockIdx.x];
@@ -901,7 +952,7 @@ int ransac_device(pcr_ctx* ctx, const pcr_pt* d_src, const pcr_pt* d_tgt, const 
             const long long want = done == 0 ? FIRST : BATCH;
             const int nb = (int)((prm->max_iteration - done) < want ? (prm->max_iteration - done) : want);
             a.first_iter = (int)done; a.n_iter = nb;
-            hipLaunchKernelGGL(ransac_kernel, dim3(nb), dim3(64), 0, ctx->stream, a, (const ransac_state*)st, dinl.as<int>(), derr.as<double>(), dT.as<double>());
+            hipLaunchKernelGGL(ransac_kernel, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, a, (const ransac_state*)st, dinl.as<int>(), derr.as<double>(), dT.as<double>());
             hipLaunchKernelGGL(ransac_walk_kernel, dim3(1), dim3(64), 0, ctx->stream, a, st, (const int*)dinl.as<int>(), (const double*)derr.as<double>(), (const double*)dT.as<double>());
             done += nb;
         }
@@ -1080,49 +1131,97 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
         chunks.clear();
     };
     // ---------------------------------------------------------------- the scans, chunk by chunk
-    for (int64_t s0 = 0; s0 < n_scans && rc == PCR_OK;) {
-        int64_t s1 = s0, pts = 0;
-        while (s1 < n_scans && s1 - s0 < CHUNK_SCANS) {
-            const int64_t n = clouds[scans[s1]].n;
-            if (n < 0 || n > 0x7fffffffll || clouds[scans[s1]].stride < 3 || (n > 0 && !clouds[scans[s1]].xyz)) { release(); return PCR_E_INVALID; }
-            if (pts > 0 && pts + n > CHUNK_PTS) break;
-            pts += n;
-            ++s1;
+    // (a share of more than ~2 M points is cut into four or more chunks so that the host threads pack chunk k + 1 into the other half of
+    // the pinned block while the device works on chunk k)
+    struct chunk_plan { std::vector<pcr_down_scan> ds; std::vector<int64_t> who; unsigned int at = 0; };
+    std::vector<chunk_plan> plans;
+    {
+        int64_t total = 0;
+        for (int64_t s = 0; s < n_scans; ++s) {
+            const pcr_cloud_ref& C = clouds[scans[s]];
+            if (C.n < 0 || C.n > 0x7fffffffll || C.stride < 3 || (C.n > 0 && !C.xyz)) return PCR_E_INVALID;
+            total += C.n;
         }
-        // (an empty scan stays without a slot: its pairs keep the identity, as when pcr_cloud_upload_f32 says PCR_E_EMPTY)
-        std::vector<pcr_down_scan> ds;
-        std::vector<int64_t> who;
-        unsigned int at = 0;
-        for (int64_t s = s0; s < s1; ++s) {
+        int64_t chunk_pts = total / 4;
+        if (chunk_pts < (2ll << 20)) chunk_pts = 2ll << 20;
+        if (chunk_pts > CHUNK_PTS) chunk_pts = CHUNK_PTS;
+        chunk_plan cur;
+        int in_chunk = 0;
+        for (int64_t s = 0; s < n_scans; ++s) {
             const int64_t n = clouds[scans[s]].n;
-            if (n == 0) continue;
-            pcr_down_scan d;
-            d.first_pt = at; d.n_pts = (unsigned int)n;
-            at += (unsigned int)n;
-            ds.push_back(d);
-            who.push_back(scans[s]);
-        }
-        s0 = s1;
-        if (ds.empty()) continue;
-        const size_t bytes = 12 * (size_t)at;
-        if (ctx->h_init_bytes < bytes) {
-            if (ctx->h_init) hipHostFree(ctx->h_init);
-            ctx->h_init = nullptr; ctx->h_init_bytes = 0;
-            if (hipHostMalloc(&ctx->h_init, bytes, hipHostMallocDefault) != hipSuccess) { release(); ctx->last_error = "no pinned memory for the scans"; return PCR_E_NOMEM; }
-            ctx->h_init_bytes = bytes;
-        }
-        float* const h_xyz = (float*)ctx->h_init;
-        parallel_for((int64_t)ds.size(), host_threads, [&](int64_t k) {
-            const pcr_cloud_ref& C = clouds[who[(size_t)k]];
-            float* dst = h_xyz + 3 * (size_t)ds[(size_t)k].first_pt;
-            float lo[3] = {C.xyz[0], C.xyz[1], C.xyz[2]}, hi[3] = {C.xyz[0], C.xyz[1], C.xyz[2]};
-            for (int64_t i = 0; i < C.n; ++i) {
-                const float* r = C.xyz + (size_t)i * (size_t)C.stride;
-                dst[3 * i] = r[0]; dst[3 * i + 1] = r[1]; dst[3 * i + 2] = r[2];
-                for (int d = 0; d < 3; ++d) { lo[d] = r[d] < lo[d] ? r[d] : lo[d]; hi[d] = r[d] > hi[d] ? r[d] : hi[d]; }
+            if (in_chunk > 0 && (in_chunk >= CHUNK_SCANS || (int64_t)cur.at + n > chunk_pts)) {
+                if (!cur.ds.empty()) plans.push_back(std::move(cur));
+                cur = chunk_plan();
+                in_chunk = 0;
             }
-            for (int d = 0; d < 3; ++d) { ds[(size_t)k].mn[d] = (double)lo[d]; ds[(size_t)k].mx[d] = (double)hi[d]; }
+            ++in_chunk;
+            if (n == 0) continue;   // (an empty scan stays without a slot: its pairs keep the identity, as when pcr_cloud_upload_f32 says PCR_E_EMPTY)
+            pcr_down_scan d;
+            d.first_pt = cur.at; d.n_pts = (unsigned int)n;
+            cur.at += (unsigned int)n;
+            cur.ds.push_back(d);
+            cur.who.push_back(scans[s]);
+        }
+        if (!cur.ds.empty()) plans.push_back(std::move(cur));
+    }
+    size_t half = 0;
+    for (auto& P : plans) half = 12 * (size_t)P.at > half ? 12 * (size_t)P.at : half;
+    half = (half + 4095) & ~(size_t)4095;
+    if (!plans.empty() && ctx->h_init_bytes < 2 * half) {
+        if (ctx->h_init) hipHostFree(ctx->h_init);
+        ctx->h_init = nullptr; ctx->h_init_bytes = 0;
+        if (hipHostMalloc(&ctx->h_init, 2 * half, hipHostMallocDefault) != hipSuccess) { ctx->last_error = "no pinned memory for the scans"; return PCR_E_NOMEM; }
+        ctx->h_init_bytes = 2 * half;
+    }
+    auto pack = [&](size_t k) {
+        chunk_plan& P = plans[k];
+        float* const h_xyz = (float*)((char*)ctx->h_init + (k & 1) * half);
+        parallel_for((int64_t)P.ds.size(), host_threads, [&](int64_t q) {
+            const pcr_cloud_ref& C = clouds[P.who[(size_t)q]];
+            float* const dst = h_xyz + 3 * (size_t)P.ds[(size_t)q].first_pt;
+            const float* const src = C.xyz;
+            const size_t st = (size_t)C.stride;
+            float lo[12], hi[12];   // four points a trip: twelve independent minima / maxima
+            for (int j = 0; j < 12; ++j) lo[j] = hi[j] = src[j % 3];
+            int64_t i = 0;
+            for (; i + 4 <= C.n; i += 4) {
+                float v[12];
+                for (int u = 0; u < 4; ++u)
+                    for (int d = 0; d < 3; ++d) v[3 * u + d] = src[(size_t)(i + u) * st + d];
+                for (int j = 0; j < 12; ++j) {
+                    dst[3 * i + j] = v[j];
+                    lo[j] = v[j] < lo[j] ? v[j] : lo[j];
+                    hi[j] = v[j] > hi[j] ? v[j] : hi[j];
+                }
+            }
+            for (; i < C.n; ++i)
+                for (int d = 0; d < 3; ++d) {
+                    const float v = src[(size_t)i * st + d];
+                    dst[3 * i + d] = v;
+                    lo[d] = v < lo[d] ? v : lo[d];
+                    hi[d] = v > hi[d] ? v : hi[d];
+                }
+            for (int d = 0; d < 3; ++d) {
+                float a = lo[d], b = hi[d];
+                for (int u = 1; u < 4; ++u) { a = lo[3 * u + d] < a ? lo[3 * u + d] : a; b = hi[3 * u + d] > b ? hi[3 * u + d] : b; }
+                P.ds[(size_t)q].mn[d] = (double)a; P.ds[(size_t)q].mx[d] = (double)b;
+            }
         });
+    };
+    if (!plans.empty()) pack(0);
+    for (size_t k = 0; k < plans.size() && rc == PCR_OK; ++k) {
+        chunk_plan& P = plans[k];
+        std::vector<pcr_down_scan>& ds = P.ds;
+        std::vector<int64_t>& who = P.who;
+        const unsigned int at = P.at;
+        const size_t bytes = 12 * (size_t)at;
+        float* const h_xyz = (float*)((char*)ctx->h_init + (k & 1) * half);
+        // the next chunk is packed (other half of the block) while the device works on this one
+        std::thread packer;
+        struct joiner { std::thread& t; ~joiner() { if (t.joinable()) t.join(); } } join_packer{packer};
+        if (k + 1 < plans.size()) {
+            try { packer = std::thread(pack, k + 1); } catch (...) { pack(k + 1); }
+        }
         lap("pack (host threads)");
         pcr_dev_block b_xyz(ctx);
         if ((rc = b_xyz.alloc(bytes))) break;
@@ -1147,12 +1246,30 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
             (rc = b_id.alloc(sizeof(unsigned int) * (size_t)g->fpfh_max_nn * ng)) || (rc = b_d2.alloc(sizeof(double) * (size_t)g->fpfh_max_nn * ng)) || (rc = b_cnt.alloc(sizeof(int) * ng)))
             break;
         const scans_view V{c.down, c.vsid, c.scan_first};
-        hipLaunchKernelGGL(normals_scans_kernel, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->normal_radius * g->normal_radius, g->normal_max_nn,
-                           b_nrm.as<double>(), fail_word(ctx));
-        hipLaunchKernelGGL(spfh_scans_kernel, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_radius * g->fpfh_radius, g->fpfh_max_nn,
-                           (const double*)b_nrm.as<double>(), b_spfh.as<double>(), b_id.as<unsigned int>(), b_d2.as<double>(), b_cnt.as<int>(), fail_word(ctx));
-        hipLaunchKernelGGL(fpfh_scans_kernel, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_max_nn, (const double*)b_spfh.as<double>(),
-                           (const unsigned int*)b_id.as<unsigned int>(), (const double*)b_d2.as<double>(), (const int*)b_cnt.as<int>(), c.fpfh);
+        pcr_dev_block b_redo(ctx);
+        if ((rc = b_redo.alloc(4 * ng))) break;
+        unsigned int* const redo = b_redo.as<unsigned int>();
+        unsigned int* const redo_n = ctx->d_counters + 117;   // [0]: normals, [1]: SPFH (zero between calls)
+        const unsigned fixed = (unsigned)(ng < (size_t)(16 * ctx->cu_count) ? ng : (size_t)(16 * ctx->cu_count));
+        const unsigned int* const none = nullptr;
+        if (hipMemsetAsync(redo_n, 0, 8, ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
+        hipLaunchKernelGGL(normals_scans_kernel<128>, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->normal_radius * g->normal_radius, g->normal_max_nn,
+                           b_nrm.as<double>(), fail_word(ctx), none, none, redo, redo_n);
+        hipLaunchKernelGGL(normals_scans_kernel<NB_CAP>, dim3(fixed), dim3(64), 0, ctx->stream, V, (long long)ng, g->normal_radius * g->normal_radius, g->normal_max_nn,
+                           b_nrm.as<double>(), fail_word(ctx), (const unsigned int*)redo, (const unsigned int*)redo_n, (unsigned int*)nullptr, (unsigned int*)nullptr);
+        // (the SPFH list is written behind the normals' one: both launches of a stage are done before the next stage's first)
+        hipLaunchKernelGGL(spfh_scans_kernel<256>, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_radius * g->fpfh_radius, g->fpfh_max_nn,
+                           (const double*)b_nrm.as<double>(), b_spfh.as<double>(), b_id.as<unsigned int>(), b_d2.as<double>(), b_cnt.as<int>(), fail_word(ctx), none, none, redo,
+                           redo_n + 1);
+        hipLaunchKernelGGL(spfh_scans_kernel<NB_CAP>, dim3(fixed), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_radius * g->fpfh_radius, g->fpfh_max_nn,
+                           (const double*)b_nrm.as<double>(), b_spfh.as<double>(), b_id.as<unsigned int>(), b_d2.as<double>(), b_cnt.as<int>(), fail_word(ctx),
+                           (const unsigned int*)redo, (const unsigned int*)(redo_n + 1), (unsigned int*)nullptr, (unsigned int*)nullptr);
+        if (g->fpfh_max_nn <= 128)
+            hipLaunchKernelGGL(fpfh_scans_kernel<128>, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_max_nn, (const double*)b_spfh.as<double>(),
+                               (const unsigned int*)b_id.as<unsigned int>(), (const double*)b_d2.as<double>(), (const int*)b_cnt.as<int>(), c.fpfh);
+        else
+            hipLaunchKernelGGL(fpfh_scans_kernel<NB_CAP>, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_max_nn, (const double*)b_spfh.as<double>(),
+                               (const unsigned int*)b_id.as<unsigned int>(), (const double*)b_d2.as<double>(), (const int*)b_cnt.as<int>(), c.fpfh);
         if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
         rc = read_fail(ctx);   // (synchronises: the chunk's scratch and the pinned block are free for the next chunk)
         lap("normals + SPFH + FPFH");
@@ -1238,7 +1355,7 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
             const int n_run = round == 0 ? nj : (int)active.size();
             const int* d_act = round == 0 ? nullptr : b_act.as<const int>();
             if (round > 0 && hipMemcpyAsync(b_act.p, active.data(), 4 * (size_t)n_run, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
-            hipLaunchKernelGGL(ransac_jobs_kernel, dim3(nb, n_run), dim3(64), 0, ctx->stream, d_jobs, d_act, rcmn);
+            hipLaunchKernelGGL(ransac_jobs_kernel, dim3((nb + 63) / 64, n_run), dim3(64), 0, ctx->stream, d_jobs, d_act, rcmn);
             hipLaunchKernelGGL(ransac_walk_jobs_kernel, dim3(n_run), dim3(64), 0, ctx->stream, d_jobs, d_act, rcmn);
             if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
             done += nb;
