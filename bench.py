@@ -667,7 +667,10 @@ def main():
         dom = max(kern, key=kern.get)
         dom_s = kern[dom] * 1e-6
         if a.nn == "grid":
-            dom_s = loop_event_us * 1e-6   # (see above)
+            # the TIMED call's own device time / its launches: the kernels stamp their 100 MHz clock (s_memrealtime) -- first kernel of the
+            # call .. end of its last pass; HIP events recorded by the host around the same call also contain the host's launch latency
+            # in front of the first kernel (`launch_us_hip_events`).  rocprofv3's per-kernel average sits just below both.
+            dom_s = r["device_ms"] / max(r["iters"], 1) * 1e-3
             algo_bytes = GRID_BYTES_PER_CORR * n_src
             traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
             try:
@@ -678,9 +681,11 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": algo_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / dom_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                         "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_correspondence": GRID_BYTES_PER_CORR,
-                        "launch_us": loop_event_us,
-                        "launch_us_source": f"HIP events on the library's stream around a {a.steps}-iteration call / {a.steps} launches (incl. launch gaps, the call's init "
-                                            "kernel and its unseeded first pass); rocprofv3 --kernel-trace average of the same kernel: profiles/r04_grid_kernel_stats.csv",
+                        "launch_us": dom_s * 1e6, "launch_us_hip_events": loop_event_us,
+                        "launch_us_source": f"the timed {a.steps}-iteration call's device time by the kernels' own clock / {a.steps} launches (incl. launch gaps, the call's init "
+                                            "kernel and its unseeded first pass); launch_us_hip_events: HIP events on the library's stream around a repeat of that call "
+                                            "(adds the host's launch latency in front of the first kernel); rocprofv3 --kernel-trace average of the same kernel: "
+                                            "profiles/r04_grid_kernel_stats.csv",
                         "frac_f64_layout": GRID_LAYOUT_BYTES_PER_CORR * n_src / dom_s / 1e9 / HBM_PEAK_GBS,
                         "traffic_source": os.path.relpath(profile_file("pmc_traffic.json"), ROOT) + " (separate rocprofv3 --pmc passes of the same command), not measured in this run",
                         "note": "working set (2 x 3.8 MB) is L2/MALL resident; this kernel is VALU-issue and latency bound, not HBM bound: see roofline_valu"}
