@@ -177,6 +177,12 @@ def test_fused_share_equals_scan_by_scan(pcp, syn, monkeypatch):
             s = prev                       # a chain: this pair's source is the last pair's target
         pairs.append((s, t, None))
         prev = t
+    rec6 = np.zeros((len(pairs[1][1]), 6), dtype=np.float32)                # 6 x f32 records (x, y, z, normal), like the dataset's .bin files
+    rec6[:, :3] = pairs[1][1]
+    rec6[:, 5] = 1.0
+    pairs.append((pairs[3][0], rec6, None))
+    cube = (np.random.default_rng(3).random((500, 3)) * 0.8 + 10.0).astype(np.float32)   # a scan inside ONE 2 m voxel: one descriptor
+    pairs.append((cube, pairs[0][1], None))
     pairs.append((pairs[0][0][:1], pairs[0][1], None))                      # one point: no descriptors, the pair starts from the identity
     pairs.append((pairs[2][0], pairs[2][1], syn.rigid_transform((0, 0, 1), 0.1, (0.5, 0.0, 0.0))))   # its own T0: not initialised
     fused = batch.native_register_share(pairs, device=0, streams=4, global_init=True, return_init=True)
