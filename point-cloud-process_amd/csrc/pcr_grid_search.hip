@@ -879,10 +879,23 @@ __device__ static inline double box_dist2(const pcr_grid_view& gv, int level, do
     return (dx + dy) + dz;
 }
 
+// minimum over the wave in every lane, on the DPP network (row_shr 1 / 2 / 4 / 8, row_bcast15, row_bcast31 bring it to lane 63; two
+// v_readlane hand it out): ~20 instructions of a few cycles each -- the __shfl_xor butterfly was six DEPENDENT ds_bpermute round trips
+// (~0.3 us) in the middle of every step of a descent.  Lanes without a source keep their own value (old = self).
+template <int CTRL, int ROW_MASK>
+__device__ static inline double dpp_min_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return vmin(v, __hiloint2double(hi, lo));
+}
 __device__ static inline double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-    return v;
+    v = dpp_min_f64<0x111, 0xf>(v);
+    v = dpp_min_f64<0x112, 0xf>(v);
+    v = dpp_min_f64<0x114, 0xf>(v);
+    v = dpp_min_f64<0x118, 0xf>(v);
+    v = dpp_min_f64<0x142, 0xa>(v);
+    v = dpp_min_f64<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 struct hard_lds {
@@ -902,13 +915,8 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
     const unsigned long long m_small = __ballot(small);
     if (m_small) {
         // exclusive prefix of the small cells' sizes over the lanes
-        unsigned int inc = small ? cnt : 0u;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int o = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += o;
-        }
-        const unsigned int total = __shfl(inc, 63, 64);
+        const unsigned int inc = wave_incl_scan_add(small ? cnt : 0u);
+        const unsigned int total = (unsigned int)__builtin_amdgcn_readlane((int)inc, 63);
         const int n_small = __popcll(m_small);
         if (small) {
             const int r = __popcll(m_small & ((1ull << lane) - 1ull));
@@ -944,10 +952,7 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
                 if (better(d2, b1.id, bd2, bid)) { bd2 = d2; bid = b1.id; bpos = jj[1]; bw[0] = b1.x; bw[1] = b1.y; bw[2] = b1.z; }
             }
         }
-        double m = bd2;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
-        bound2 = fmin(bound2, m);
+        bound2 = fmin(bound2, wave_min(bd2));
     }
     // big cells: push (far ones first so that the nearest is split first); without room they are read whole
     const bool big = valid && !small && bdist <= bound2;
@@ -974,10 +979,7 @@ __device__ static inline void hard_disperse(const pcr_grid_view& gv, hard_lds* L
             scan_range(gv.pts, ss + lane, ee, 64, ax, ay, az, bd2, bid, bpos, bw);
             n_pts += ee - ss;
         }
-        double m = bd2;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
-        bound2 = fmin(bound2, m);
+        bound2 = fmin(bound2, wave_min(bd2));
     }
 }
 
@@ -1091,20 +1093,31 @@ __device__ __forceinline__ static void hard_search(const pcr_grid_view& gv, hard
             ++h_steps;
         }
     }
-    const unsigned int own_pos = bpos;
+    // the lanes' bests meet: the smallest distance over the wave (DPP), then -- among the lanes that hold it: one, unless two points are
+    // exactly equidistant -- the smallest id; the winner's lane hands everything out by v_readlane (no LDS, no butterfly)
+    {
+        const double m = wave_min(bd2);
+        unsigned long long cm = __ballot(bpos != POS_NONE && bd2 == m);
+        if (!cm) { bd2 = DBL_MAX; bid = ID_NONE; bpos = POS_NONE; if (win) { win[0] = win[1] = win[2] = 0.0; } return; }
+        int wl = (int)__ffsll((long long)cm) - 1;
+        cm &= cm - 1;
+        if (cm) {   // (rare) ties in distance: lowest id
+            long long best_id = ((long long)__builtin_amdgcn_readlane((int)(bid >> 32), wl) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)bid, wl);
+            while (cm) {
+                const int l = (int)__ffsll((long long)cm) - 1;
+                cm &= cm - 1;
+                const long long id_l = ((long long)__builtin_amdgcn_readlane((int)(bid >> 32), l) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)bid, l);
+                if (id_l < best_id) { best_id = id_l; wl = l; }
+            }
+        }
+        bd2 = m;
+        bid = ((long long)__builtin_amdgcn_readlane((int)(bid >> 32), wl) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)bid, wl);
+        bpos = (unsigned int)__builtin_amdgcn_readlane((int)bpos, wl);
+        if (win) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double od2 = __shfl_xor(bd2, off, 64);
-        const long long oid = __shfl_xor(bid, off, 64);
-        const unsigned int opos = __shfl_xor(bpos, off, 64);
-        if (better(od2, oid, bd2, bid)) { bd2 = od2; bid = oid; bpos = opos; }
-    }
-    if (win) {   // the lane that scanned the winner hands its coordinates over through LDS (every point is scanned by one lane)
-        double* xw = reinterpret_cast<double*>(L->fl_off);
-        wave_sync();
-        if (bpos != POS_NONE && own_pos == bpos) { xw[0] = bw[0]; xw[1] = bw[1]; xw[2] = bw[2]; }
-        wave_sync();
-        win[0] = xw[0]; win[1] = xw[1]; win[2] = xw[2];
+            for (int k = 0; k < 3; ++k)
+                win[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bw[k]), wl), __builtin_amdgcn_readlane(__double2loint(bw[k]), wl));
+        }
     }
 }
 
