@@ -166,3 +166,45 @@ __device__ static inline void xform_apply(const pcr_xform& x, const pcr_pt& p, d
     *ay = ((x.r[3] * p.x + x.r[4] * p.y) + x.r[5] * p.z) + x.t[1];
     *az = ((x.r[6] * p.x + x.r[7] * p.y) + x.r[8] * p.z) + x.t[2];
 }
+
+// ---------------------------------------------------------------- wave64 reductions on the DPP network
+// row_shr 1 / 2 / 4 / 8, then row_bcast15 / row_bcast31: six VALU instructions of a few cycles each, no LDS traffic (a __shfl_up / __shfl_xor
+// chain is six DEPENDENT ds_bpermute round trips).  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ static inline unsigned int dpp_u32(unsigned int identity, unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ static inline unsigned int wave_incl_scan_add(unsigned int v) {
+    v += dpp_u32<0x111, 0xf>(0u, v);
+    v += dpp_u32<0x112, 0xf>(0u, v);
+    v += dpp_u32<0x114, 0xf>(0u, v);
+    v += dpp_u32<0x118, 0xf>(0u, v);
+    v += dpp_u32<0x142, 0xa>(0u, v);   // row_bcast15 into rows 1 and 3
+    v += dpp_u32<0x143, 0xc>(0u, v);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ static inline unsigned int wave_excl_scan_u32(unsigned int v, int lane, unsigned int* total) {
+    const unsigned int inc = wave_incl_scan_add(v);
+    *total = __builtin_amdgcn_readlane((int)inc, 63);
+    return inc - v;
+}
+// minimum / maximum over the wave in every lane (lanes without a source keep their own value; lane 63 ends with the result)
+__device__ static inline int wave_min_i32(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ static inline int wave_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+

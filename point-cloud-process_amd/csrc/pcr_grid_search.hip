@@ -153,21 +153,6 @@ __device__ static inline void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Wave64 inclusive scans on the DPP network (row_shr 1/2/4/8, then row_bcast15 / row_bcast31): six VALU
-// instructions, no LDS traffic (a __shfl_up scan is six ds_bpermute round trips).
-template <int CTRL, int ROW_MASK>
-__device__ static inline unsigned int dpp_u32(unsigned int identity, unsigned int v) {
-    return (unsigned int)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ static inline unsigned int wave_incl_scan_add(unsigned int v) {
-    v += dpp_u32<0x111, 0xf>(0u, v);
-    v += dpp_u32<0x112, 0xf>(0u, v);
-    v += dpp_u32<0x114, 0xf>(0u, v);
-    v += dpp_u32<0x118, 0xf>(0u, v);
-    v += dpp_u32<0x142, 0xa>(0u, v);   // row_bcast15 into rows 1 and 3
-    v += dpp_u32<0x143, 0xc>(0u, v);   // row_bcast31 into rows 2 and 3
-    return v;
-}
 __device__ static inline unsigned int wave_incl_scan_max(unsigned int v) {
     v = max(v, dpp_u32<0x111, 0xf>(0u, v));
     v = max(v, dpp_u32<0x112, 0xf>(0u, v));
@@ -210,12 +195,6 @@ __device__ static inline int row16_max(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
     return v;
-}
-
-__device__ static inline unsigned int wave_excl_scan_u32(unsigned int v, int lane, unsigned int* total) {
-    const unsigned int inc = wave_incl_scan_add(v);
-    *total = __builtin_amdgcn_readlane((int)inc, 63);
-    return inc - v;
 }
 
 struct wt_xyz { double x, y, z; };  // the 24 coordinate bytes of a pcr_pt record

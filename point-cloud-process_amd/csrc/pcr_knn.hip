@@ -377,16 +377,8 @@ __device__ static inline void kt_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ static inline int kt_wave_min(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-    return v;
-}
-__device__ static inline int kt_wave_max(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
-}
+__device__ static inline int kt_wave_min(int v) { return wave_min_i32(v); }   // (DPP network: pcr_grid_dev.h)
+__device__ static inline int kt_wave_max(int v) { return wave_max_i32(v); }
 
 // LPQ lanes per query (64 / LPQ queries per wave), PASSES passes of at most ROUNDS staging rounds.  `order`: the query ids to do, n
 // of them (n = *count_p when count_p is given: the list the first stage left).
@@ -473,16 +465,11 @@ __device__ static void knn_tile_one(const pcr_grid_view& gv, knn_tile_lds* L, co
                 found = lookup_cell(gv.table[level], gv.mask[level], (unsigned int)X, (unsigned int)Y, (unsigned int)Z, &cs, &ce);
             }
             const unsigned long long fm = __ballot(found);
-            unsigned int cnt = found ? ce - cs : 0u, inc = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned int o = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += o;
-            }
+            const unsigned int cnt = found ? ce - cs : 0u, inc = wave_incl_scan_add(cnt);
             const unsigned int li = n_list + (unsigned int)__popcll(fm & ((1ull << lane) - 1ull));
             if (found && li < KT_LIST) { L->c_start[li] = cs; L->c_pre[li] = n_pts + inc - cnt; }
             n_list += (unsigned int)__popcll(fm);
-            n_pts += __shfl(inc, 63, 64);
+            n_pts += (unsigned int)__builtin_amdgcn_readlane((int)inc, 63);
             if (n_list > KT_LIST) { too_much = true; break; }
         }
         if (too_much || n_pts > (unsigned int)(ROUNDS * KT_PTS)) break;   // too much for this stage
