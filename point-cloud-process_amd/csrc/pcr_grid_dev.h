@@ -207,4 +207,29 @@ __device__ static inline int wave_max_i32(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
     return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ static inline double vmin(double a, double b) {  // plain v_min_f64 (fmin() adds two canonicalising v_max)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// binary64 minimum over the wave in every lane: ~20 instructions of a few cycles each -- the __shfl_xor butterfly was six DEPENDENT
+// ds_bpermute round trips (~0.3 us) in the middle of every step of a descent.  Lanes without a source keep their own value (old = self).
+template <int CTRL, int ROW_MASK>
+__device__ static inline double dpp_min_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return vmin(v, __hiloint2double(hi, lo));
+}
+__device__ static inline double wave_min_f64(double v) {
+    v = dpp_min_f64<0x111, 0xf>(v);
+    v = dpp_min_f64<0x112, 0xf>(v);
+    v = dpp_min_f64<0x114, 0xf>(v);
+    v = dpp_min_f64<0x118, 0xf>(v);
+    v = dpp_min_f64<0x142, 0xa>(v);
+    v = dpp_min_f64<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ static inline long long readlane_i64(long long v, int l) {   // l: wave-uniform
+    return ((long long)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)v, l);
+}
 

@@ -71,12 +71,6 @@ __device__ static inline void scan_range(const pcr_pt* __restrict__ pts, unsigne
     }
 }
 
-__device__ static inline double vmin(double a, double b) {  // plain v_min_f64 (fmin() adds two canonicalising v_max)
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 __device__ static inline float fmin3(float a, float b, float c) {  // v_min3_f32 (inputs are never NaN here)
     float r;
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -858,24 +852,7 @@ __device__ static inline double box_dist2(const pcr_grid_view& gv, int level, do
     return (dx + dy) + dz;
 }
 
-// minimum over the wave in every lane, on the DPP network (row_shr 1 / 2 / 4 / 8, row_bcast15, row_bcast31 bring it to lane 63; two
-// v_readlane hand it out): ~20 instructions of a few cycles each -- the __shfl_xor butterfly was six DEPENDENT ds_bpermute round trips
-// (~0.3 us) in the middle of every step of a descent.  Lanes without a source keep their own value (old = self).
-template <int CTRL, int ROW_MASK>
-__device__ static inline double dpp_min_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return vmin(v, __hiloint2double(hi, lo));
-}
-__device__ static inline double wave_min(double v) {
-    v = dpp_min_f64<0x111, 0xf>(v);
-    v = dpp_min_f64<0x112, 0xf>(v);
-    v = dpp_min_f64<0x114, 0xf>(v);
-    v = dpp_min_f64<0x118, 0xf>(v);
-    v = dpp_min_f64<0x142, 0xa>(v);
-    v = dpp_min_f64<0x143, 0xc>(v);
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
+__device__ static inline double wave_min(double v) { return wave_min_f64(v); }   // (DPP network: pcr_grid_dev.h)
 
 struct hard_lds {
     hard_entry stack[HARD_STACK];

@@ -510,10 +510,41 @@ __device__ static void knn_tile_one(const pcr_grid_view& gv, knn_tile_lds* L, co
             }
         }
         kt_wave_sync();
-        // ---- the LPQ lists of a query meet: exchange with lane ^ 1, lane ^ 2, ...; every entry of the partner's list is inserted
-        // (disjoint quarters: no duplicates), so all four lanes end with the same k best
+        // ---- the lanes' lists of a query meet.  One query per wave: k times over, the smallest HEAD of the 64 sorted lists (DPP minimum,
+        // ties to the lowest id) is the next entry of the merged list and leaves its lane's list -- ~70 instructions per entry.  (The
+        // butterfly below inserts every entry of the partner's list, six rounds of K x K compare-and-swaps and 4 K ds_bpermute: 12 000
+        // instructions per pass at K = 16, most of the wave-per-query stage's time.)
+        if (LPQ == 64) {
+            double md[K];
+            long long mi[K];
 #pragma unroll
-        for (int xm = 1; xm < LPQ; xm <<= 1) {
+            for (int j = 0; j < K; ++j) {
+                md[j] = DBL_MAX; mi[j] = 0x7fffffffffffffffll;
+                const double m = j < k ? wave_min_f64(bd[0]) : DBL_MAX;
+                if (m < DBL_MAX) {   // (wave-uniform; DBL_MAX: the lists are exhausted)
+                    unsigned long long cm = __ballot(bd[0] == m);
+                    int wl = (int)__ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    long long wid = readlane_i64(bi[0], wl);
+                    while (cm) {   // equal distances: the lowest id
+                        const int l = (int)__ffsll((long long)cm) - 1;
+                        cm &= cm - 1;
+                        const long long id_l = readlane_i64(bi[0], l);
+                        if (id_l < wid) { wid = id_l; wl = l; }
+                    }
+                    md[j] = m; mi[j] = wid;
+                    if (lane == wl) {
+#pragma unroll
+                        for (int u = 0; u + 1 < K; ++u) { bd[u] = bd[u + 1]; bi[u] = bi[u + 1]; }
+                        bd[K - 1] = DBL_MAX; bi[K - 1] = 0x7fffffffffffffffll;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) { bd[j] = md[j]; bi[j] = mi[j]; }
+        }
+#pragma unroll
+        for (int xm = 1; xm < (LPQ == 64 ? 1 : LPQ); xm <<= 1) {
             double od[K];
             long long oi[K];
 #pragma unroll
