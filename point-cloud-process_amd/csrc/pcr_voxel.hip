@@ -613,33 +613,26 @@ int pcr_voxel_downsample_scans(pcr_ctx* ctx, const float* d_xyz, int64_t n_pts, 
                            (const unsigned int*)b_heads.as<unsigned int>(), (const unsigned int*)n_groups, n, 2, d_full, (double*)nullptr, (const unsigned int*)big_count,
                            (const unsigned int*)b_big.as<unsigned int>());
     }
-    unsigned int *d_first = nullptr, *d_vsid = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, 4 * (size_t)(n_scans + 1), (void**)&d_first))) return rc;
-    // (the voxel count is at most the point count; the scan-of-voxel list is cut to size below)
-    pcr_dev_block b_vsid(ctx);
-    if ((rc = b_vsid.alloc(4 * (size_t)n))) { pcr_dev_free(ctx, d_first, 4 * (size_t)(n_scans + 1)); return rc; }
+    // (blocks that go back to the arena on every error path; handed to the caller at the end)
+    pcr_dev_block b_first(ctx), b_vsid(ctx), b_down(ctx), b_vs(ctx);
+    if ((rc = b_first.alloc(4 * (size_t)(n_scans + 1))) || (rc = b_vsid.alloc(4 * (size_t)n))) return rc;   // (the voxel count is at most the point count)
+    unsigned int* const d_first = b_first.as<unsigned int>();
     const unsigned sgrid = (unsigned)(grid_n < 4 * ctx->cu_count ? grid_n : 4 * ctx->cu_count);
     hipLaunchKernelGGL(scans_first_kernel, dim3(sgrid), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys2, (const unsigned int*)b_heads.as<unsigned int>(),
                        (const unsigned int*)n_groups, LB, n_scans, d_first, b_vsid.as<unsigned int>());
     hipLaunchKernelGGL(scans_rows_kernel, dim3(sgrid), dim3(256), 0, ctx->stream, d_full, (const unsigned int*)b_vsid.as<unsigned int>(), (const unsigned int*)d_first,
                        (const unsigned int*)n_groups);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) rc = pcr_d2h_small(ctx, scan_first_host, d_first, 4 * (size_t)(n_scans + 1));   // (synchronises)
-    if (e != hipSuccess || rc) {
-        pcr_dev_free(ctx, d_first, 4 * (size_t)(n_scans + 1));
-        if (e != hipSuccess) { ctx->last_error = std::string("voxel filter (scans): ") + hipGetErrorString(e); return PCR_E_HIP; }
-        return rc;
-    }
+    PCR_HIP(ctx, hipGetLastError());
+    if ((rc = pcr_d2h_small(ctx, scan_first_host, d_first, 4 * (size_t)(n_scans + 1)))) return rc;   // (synchronises)
     const int64_t ng = (int64_t)scan_first_host[n_scans];
     // cut to size
-    pcr_pt* d_down = nullptr;
-    if ((rc = pcr_dev_alloc(ctx, sizeof(pcr_pt) * (size_t)(ng > 0 ? ng : 1), (void**)&d_down)) || (rc = pcr_dev_alloc(ctx, 4 * (size_t)(ng > 0 ? ng : 1), (void**)&d_vsid))) {
-        if (d_down) pcr_dev_free(ctx, d_down, sizeof(pcr_pt) * (size_t)(ng > 0 ? ng : 1));
-        pcr_dev_free(ctx, d_first, 4 * (size_t)(n_scans + 1));
-        return rc;
-    }
+    const size_t ng1 = (size_t)(ng > 0 ? ng : 1);
+    if ((rc = b_down.alloc(sizeof(pcr_pt) * ng1)) || (rc = b_vs.alloc(4 * ng1))) return rc;
+    pcr_pt* const d_down = b_down.as<pcr_pt>();
+    unsigned int* const d_vsid = b_vs.as<unsigned int>();
     PCR_HIP(ctx, hipMemcpyAsync(d_down, d_full, sizeof(pcr_pt) * (size_t)ng, hipMemcpyDeviceToDevice, ctx->stream));
     PCR_HIP(ctx, hipMemcpyAsync(d_vsid, b_vsid.p, 4 * (size_t)ng, hipMemcpyDeviceToDevice, ctx->stream));
+    b_first.p = nullptr; b_down.p = nullptr; b_vs.p = nullptr;   // the caller's now
     *down_out = d_down; *vsid_out = d_vsid; *scan_first_out = d_first; *ng_out = ng;
     return PCR_OK;
 }
