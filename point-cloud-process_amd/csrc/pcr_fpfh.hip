@@ -1170,7 +1170,11 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
     if (!plans.empty() && ctx->h_init_bytes < 2 * half) {
         if (ctx->h_init) hipHostFree(ctx->h_init);
         ctx->h_init = nullptr; ctx->h_init_bytes = 0;
-        if (hipHostMalloc(&ctx->h_init, 2 * half, hipHostMallocDefault) != hipSuccess) { ctx->last_error = "no pinned memory for the scans"; return PCR_E_NOMEM; }
+        if (hipHostMalloc(&ctx->h_init, 2 * half, hipHostMallocDefault) != hipSuccess) {   // no pinned block of that size: the scans go one by one
+            (void)hipGetLastError();
+            ctx->h_init = nullptr;
+            return PCR_E_UNSUPPORTED;
+        }
         ctx->h_init_bytes = 2 * half;
     }
     auto pack = [&](size_t k) {
