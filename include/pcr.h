@@ -298,6 +298,8 @@ PCR_API int pcr_global_registration(pcr_ctx* ctx, const pcr_prep* source, const 
  *     whose T0 is NULL: pcr_preprocess of every scan such a pair uses, pcr_global_registration per pair (the same ransac seed
  *     for every pair, so a pair's result does not depend on which other pairs share the call); a pair for which no hypothesis
  *     passes the checkers starts from identity.  T_init_out (n_pairs x 16, may be NULL) receives the transforms ICP started from.
+ *     (Inside, the stage runs fused for the whole call on the first context -- every scan down-sampled by one sort, every later step
+ *     one launch for all scans / all pairs -- and scan by scan for a share that does not fit that path: the same results bit for bit.)
  *   then icp_point2point (main.py:211) for every pair through pcr_icp_batch's fused stages.
  * results / status_out as pcr_icp_batch.                                                                                   */
 typedef struct pcr_cloud_ref {
