@@ -27,6 +27,10 @@
 #include "pcr_linalg.h"
 
 constexpr int NB_CAP = 1024;
+// clouds of up to this many points are searched without an index (brute_view; the fused initialisation takes only such scans)
+#ifndef PCR_HYBRID_BRUTE_MAX
+#define PCR_HYBRID_BRUTE_MAX 4096
+#endif
 
 struct __attribute__((aligned(16))) nb_entry {
     double d2;
@@ -774,9 +778,286 @@ struct init_job {
     int* inl;                         // hypothesis scratch of a batch
     double *err2, *Tout;
     unsigned long long seed;
+    // matrix-core operands of both descriptor sets (mfma_ops_kernel): as the sweep's targets, as its queries; squared norms; largest norm
+    const double *ta, *tb, *qa, *qb, *n2a, *n2b, *mxa, *mxb;
+    const unsigned int *mra, *mrb;    // row of the smallest norm (lowest row on ties) of either set: the answer for an all-zero query
 };
 constexpr int JOB_SPLITS = 8;
 __device__ static inline long long job_per(long long nb) { return ((nb + JOB_SPLITS - 1) / JOB_SPLITS + FM_TILE - 1) / FM_TILE * FM_TILE; }
+
+// ---- feature matching on the matrix cores, exact.
+// |a - b|^2 = |a|^2 + (|b|^2 - 2 a.b): the bracket is a K = 36 contraction [-2 b_0 .. -2 b_32, |b|^2, 0, 0] . [a_0 .. a_32, 1, 0, 0] -- nine
+// v_mfma_f64_16x16x4_f64 per 16 targets x 16 queries -- and |a|^2 does not move a query's argmin.  The sweep is only a FILTER: per query and
+// lane the running minimum m of the bracket and the targets within tau of it are kept (the true winner is within tau of the running minimum
+// when it is met: the minimum only falls); tau = 2^-40 (|a| + max |b|)^2 bounds twice the difference between the bracket + |a|^2 and the
+// reference sum ((a_0 - b_0)^2 + ...) + ... of 33 rounded terms (< 80 roundings of quantities <= (|a| + |b|)^2 on either side).  The kept
+// targets -- one, unless descriptors are (nearly) equidistant -- are then evaluated in the reference form, in index order: same index, same
+// d^2, ties to the lowest row, as feature_match_body.  A lane that met more than two candidates evaluates its whole share directly.
+// Operand layout (mfma_ops_kernel): ops[tile][step 0..8][lane] with lane l <-> (row = 16 tile + (l & 15), k = 4 step + (l >> 4)), the layout
+// both the A operand (rows = targets) and the B operand (columns = queries) of the instruction use: one coalesced 512-byte read per step.
+typedef double fm_v4 __attribute__((ext_vector_type(4)));
+constexpr int FM_STEPS = 9;          // 36 = 33 dimensions + the norm / one slot + 2 zeros
+constexpr int FM_NT = 4;             // query tiles of 16 per wave
+constexpr double FM_TAU_REL = 9.094947017729282e-13;   // 2^-40
+// Identical descriptors are common -- the points of a scan whose neighbourhoods hold a single other point all get the same one: groups of
+// 50 - 70 rows in a 1 000-row scan -- and a query that is one of them ties with every target that is: dozens of exact evaluations behind the
+// sweep.  A row that repeats an EARLIER row of its scan can never be the answer (same distance, higher index): it is taken out of the
+// sweep's targets (its operand row becomes a padding row).  One block per scan: a hash table in LDS keeps the lowest row of every hash
+// tag; a row whose tag's lowest row is an earlier one compares itself with that row bit by bit.
+__global__ void __launch_bounds__(1024) dup_rows_kernel(const double* __restrict__ fpfh /* (ng,33) */, const unsigned int* __restrict__ scan_first,
+                                                        unsigned char* __restrict__ dup /* (ng): 1 = repeats an earlier row of its scan */) {
+    // open-addressing table in LDS: hash tag (high 32 bits) << 32 | lowest row seen with that tag; all ones = free
+    constexpr unsigned int SLOTS = 2 * PCR_HYBRID_BRUTE_MAX;
+    static_assert(SLOTS * 8 <= 65536 && (SLOTS & (SLOTS - 1)) == 0, "the table fits the block's LDS");
+    __shared__ unsigned long long tab[SLOTS];
+    const unsigned int base = scan_first[blockIdx.x], n = scan_first[blockIdx.x + 1] - base;   // (n <= PCR_HYBRID_BRUTE_MAX: checked by the caller)
+    for (unsigned int i = threadIdx.x; i < SLOTS; i += 1024) tab[i] = ~0ull;
+    __syncthreads();
+    auto row_hash = [&](unsigned int j) {
+        const unsigned long long* x = reinterpret_cast<const unsigned long long*>(fpfh + 33 * (size_t)(base + j));
+        unsigned long long h = 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < 33; ++k) { h ^= x[k]; h *= 0xD1B54A32D192ED03ull; h ^= h >> 29; }
+        return h;
+    };
+    for (unsigned int j = threadIdx.x; j < n; j += 1024) {
+        const unsigned long long h = row_hash(j), mine = (h & 0xffffffff00000000ull) | j;
+        for (unsigned int slot = (unsigned int)h & (SLOTS - 1);; slot = (slot + 1) & (SLOTS - 1)) {
+            const unsigned long long cur = tab[slot];
+            if (cur == ~0ull) {
+                if (atomicCAS(&tab[slot], ~0ull, mine) == ~0ull) break;
+                --slot;   // somebody took it first: look at it again
+                continue;
+            }
+            if ((cur >> 32) == (h >> 32)) { atomicMin(&tab[slot], mine); break; }   // same tag: the lowest row stays
+        }
+    }
+    __syncthreads();
+    for (unsigned int j = threadIdx.x; j < n; j += 1024) {
+        const unsigned long long h = row_hash(j);
+        unsigned int rep = j;
+        for (unsigned int slot = (unsigned int)h & (SLOTS - 1);; slot = (slot + 1) & (SLOTS - 1)) {
+            const unsigned long long cur = tab[slot];
+            if (cur == ~0ull) break;
+            if ((cur >> 32) == (h >> 32)) { rep = (unsigned int)cur; break; }
+        }
+        unsigned char d = 0;
+        if (rep < j) {   // the same tag: the rows themselves decide (a colliding tag leaves the row a target: harmless)
+            const unsigned long long* xi = reinterpret_cast<const unsigned long long*>(fpfh + 33 * (size_t)(base + rep));
+            const unsigned long long* xj = reinterpret_cast<const unsigned long long*>(fpfh + 33 * (size_t)(base + j));
+            bool same = true;
+            for (int k = 0; k < 33; ++k) same = same && xi[k] == xj[k];
+            d = same ? 1 : 0;
+        }
+        dup[base + j] = d;
+    }
+}
+
+__global__ void __launch_bounds__(64) mfma_ops_kernel(const double* __restrict__ fpfh /* (ng,33) */, const unsigned int* __restrict__ scan_first, int n_scans,
+                                                      const unsigned int* __restrict__ tile_first /* [n_scans + 1] */, const unsigned char* __restrict__ dup,
+                                                      double* __restrict__ op_t, double* __restrict__ op_q,
+                                                      double* __restrict__ norm2 /* (ng) */, unsigned long long* __restrict__ max_norm2 /* [n_scans], bits of a double */) {
+    const unsigned int tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    int lo = 0, hi = n_scans - 1;   // the scan that owns this tile
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_first[mid] <= tile) lo = mid;
+        else hi = mid - 1;
+    }
+    const unsigned int base = scan_first[lo], n = scan_first[lo + 1] - base, lt = tile - tile_first[lo];
+    const unsigned int row = 16u * lt + (unsigned int)(lane & 15);
+    const bool live = row < n;
+    const double* x = fpfh + 33 * (size_t)(base + row);
+    double nn = 0.0;
+    if (live)
+        for (int k = 0; k < 33; ++k) nn += x[k] * x[k];
+    if (live && lane < 16) {
+        norm2[base + row] = nn;
+        atomicMax(max_norm2 + lo, (unsigned long long)__double_as_longlong(nn));   // (non-negative doubles order like their bit patterns)
+    }
+#pragma unroll
+    for (int st = 0; st < FM_STEPS; ++st) {
+        const int k = 4 * st + (lane >> 4);
+        double vt, vq;
+        if (live) { vt = k < 33 ? -2.0 * x[k] : (k == 33 ? nn : 0.0); vq = k < 33 ? x[k] : (k == 33 ? 1.0 : 0.0); }
+        else { vt = k == 33 ? 1e300 : 0.0; vq = 0.0; }   // a padding row never wins as a target, and is nobody's query
+        if (live && dup[base + row]) vt = k == 33 ? 1e300 : 0.0;   // a repeated row: still a query, never a target
+        op_t[((size_t)tile * FM_STEPS + st) * 64 + lane] = vt;
+        op_q[((size_t)tile * FM_STEPS + st) * 64 + lane] = vq;
+    }
+}
+
+// per scan: the row with the smallest squared norm, lowest row on ties (one block per scan)
+__global__ void __launch_bounds__(256) min_norm_row_kernel(const double* __restrict__ norm2, const unsigned int* __restrict__ scan_first, unsigned int* __restrict__ min_row) {
+    __shared__ double s_v[256];
+    __shared__ unsigned int s_r[256];
+    const unsigned int base = scan_first[blockIdx.x], n = scan_first[blockIdx.x + 1] - base;
+    double v = DBL_MAX;
+    unsigned int r = 0xffffffffu;
+    for (unsigned int i = threadIdx.x; i < n; i += 256) {
+        const double x = norm2[base + i];
+        if (x < v) { v = x; r = i; }   // (ascending rows per thread: the first one met stays on ties)
+    }
+    s_v[threadIdx.x] = v; s_r[threadIdx.x] = r;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const double ov = s_v[threadIdx.x + off];
+            const unsigned int orow = s_r[threadIdx.x + off];
+            if (ov < s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && orow < s_r[threadIdx.x])) { s_v[threadIdx.x] = ov; s_r[threadIdx.x] = orow; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) min_row[blockIdx.x] = s_r[0];
+}
+
+__device__ static inline double fm_exact(const double* __restrict__ a, const double* __restrict__ b) {   // feature_match_body's sum, term by term
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 33; ++k) { const double d = a[k] - b[k]; s += d * d; }
+    return s;
+}
+
+__global__ void __launch_bounds__(256) feature_match_mfma_jobs_kernel(const init_job* __restrict__ jobs, int mutual, int splits /* target splits = gridDim.y */) {
+    const init_job J = jobs[blockIdx.z >> 1];
+    const bool back = (blockIdx.z & 1) != 0;
+    if (back && !mutual) return;
+    const int na = back ? J.nb : J.na, nb = back ? J.na : J.nb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qt0 = ((int)blockIdx.x * 4 + wave) * FM_NT;   // this wave's first query tile
+    if (qt0 * 16 >= na) return;
+    const double* const A = back ? J.fb : J.fa;     // queries, reference layout
+    const double* const B = back ? J.fa : J.fb;     // targets
+    const double* const opq = back ? J.qb : J.qa;
+    const double* const opt = back ? J.ta : J.tb;
+    const double* const n2q = back ? J.n2b : J.n2a;
+    const double* const n2t = back ? J.n2a : J.n2b;
+    const unsigned int* const mrt = back ? J.mra : J.mrb;
+    const double bmax = sqrt(*(back ? J.mxa : J.mxb));
+    int* const idx_out = back ? J.ci_ba : J.ci_ab;
+    double* const d2_out = back ? J.cd_ba : J.cd_ab;
+    const int q_tiles = (na + 15) >> 4;
+    double bq[FM_NT][FM_STEPS];
+    double tau[FM_NT], m[FM_NT], hi[FM_NT];   // hi = m + tau, refreshed when m moves
+    int c0[FM_NT], c1[FM_NT], cnt[FM_NT];
+    bool zq[FM_NT];   // an all-zero query (the descriptor of an isolated point): its distance to target j is |b_j|^2 -- term for term the sum
+                      // mfma_ops_kernel stored -- and it ties with every all-zero target: answered from min_norm_row_kernel's table
+#pragma unroll
+    for (int tt = 0; tt < FM_NT; ++tt) {
+        const bool tile_ok = qt0 + tt < q_tiles;
+#pragma unroll
+        for (int st = 0; st < FM_STEPS; ++st) bq[tt][st] = tile_ok ? opq[((size_t)(qt0 + tt) * FM_STEPS + st) * 64 + lane] : 0.0;
+        const int qi = (qt0 + tt) * 16 + (lane & 15);
+        const double qn = qi < na ? sqrt(n2q[qi]) : 0.0;
+        zq[tt] = splits == 1 && qi < na && qn == 0.0;
+        tau[tt] = FM_TAU_REL * (qn + bmax) * (qn + bmax);
+        m[tt] = DBL_MAX; hi[tt] = DBL_MAX; c0[tt] = c1[tt] = -1; cnt[tt] = 0;
+    }
+    // (one wave sweeps a whole split of the targets -- all of them by default: the exact evaluation behind the sweep is per (query, split))
+    const long long per = ((nb + splits - 1) / splits + 15) / 16 * 16;
+    const int tb = (int)((long long)blockIdx.y * per), te = (int)(tb + per < nb ? tb + per : nb);
+    const int t_end = (te + 15) >> 4;
+    double a_next[FM_STEPS];
+#pragma unroll
+    for (int st = 0; st < FM_STEPS; ++st) a_next[st] = (tb >> 4) < t_end ? opt[((size_t)(tb >> 4) * FM_STEPS + st) * 64 + lane] : 0.0;
+    for (int t = tb >> 4; t < t_end; ++t) {
+        double a[FM_STEPS];
+#pragma unroll
+        for (int st = 0; st < FM_STEPS; ++st) a[st] = a_next[st];
+        if (t + 1 < t_end) {   // the next tile's operands are on their way while this one is multiplied
+#pragma unroll
+            for (int st = 0; st < FM_STEPS; ++st) a_next[st] = opt[((size_t)(t + 1) * FM_STEPS + st) * 64 + lane];
+        }
+        fm_v4 acc[FM_NT];
+#pragma unroll
+        for (int tt = 0; tt < FM_NT; ++tt) acc[tt] = fm_v4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < FM_STEPS; ++st)
+#pragma unroll
+            for (int tt = 0; tt < FM_NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st], bq[tt][st], acc[tt], 0, 0, 0);
+        const int j0 = t * 16 + (lane >> 4);   // this lane's four target rows of the tile: j0, j0 + 4, j0 + 8, j0 + 12 (the D layout of the instruction)
+        // (almost every tile holds nothing near a lane's running minimum: one comparison of the four values' minimum against m + tau decides)
+#pragma unroll
+        for (int tt = 0; tt < FM_NT; ++tt) {
+            const double vm = vmin(vmin(acc[tt][0], acc[tt][1]), vmin(acc[tt][2], acc[tt][3]));
+            if (vm <= hi[tt]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = acc[tt][r];
+                    const int j = j0 + 4 * r;
+                    if (v < m[tt] - tau[tt]) { m[tt] = v; c0[tt] = j; cnt[tt] = 1; }
+                    else if (v <= m[tt] + tau[tt]) {
+                        if (cnt[tt] == 1) c1[tt] = j;
+                        cnt[tt] = cnt[tt] < 3 ? cnt[tt] + 1 : 3;
+                        m[tt] = v < m[tt] ? v : m[tt];
+                    }
+                }
+                hi[tt] = m[tt] + tau[tt];
+            }
+        }
+    }
+    // ---- the candidates in the reference form; the four lanes of a query meet
+#pragma unroll
+    for (int tt = 0; tt < FM_NT; ++tt) {
+        const int qi = (qt0 + tt) * 16 + (lane & 15);
+        double best = DBL_MAX;
+        int bj = -1;
+        // only a lane whose share's minimum is within tau of the query's minimum over all four shares can hold the winner (usually one of four)
+        double gm = m[tt];
+        gm = vmin(gm, __shfl_xor(gm, 16, 64));
+        gm = vmin(gm, __shfl_xor(gm, 32, 64));
+        const bool need = qi < na && !zq[tt] && cnt[tt] >= 1 && m[tt] <= gm + tau[tt];
+        if (!need) cnt[tt] = 0;
+        if (zq[tt] && (lane >> 4) == 0) { bj = (int)*mrt; best = n2t[bj]; }
+        if (need) {
+            const double* const aq = A + 33 * (size_t)qi;
+            if (cnt[tt] <= 2) {
+                if (cnt[tt] >= 1 && c0[tt] < te) { best = fm_exact(aq, B + 33 * (size_t)c0[tt]); bj = c0[tt]; }
+                if (cnt[tt] == 2 && c1[tt] < te) {
+                    const double d = fm_exact(aq, B + 33 * (size_t)c1[tt]);
+                    if (d < best) { best = d; bj = c1[tt]; }
+                }
+            }   // (cnt = 3: more than two candidates -- the second sweep below)
+        }
+        // (Nearly) equidistant descriptors are not rare: an isolated point has an all-zero descriptor, and every scan has a few -- a query
+        // that is one ties with all of the target's.  Such a lane knows its share's final minimum now: the wave multiplies once more and the
+        // lane evaluates, in index order, exactly the rows within tau of it (its whole share directly was 132 evaluations of 66 loads).
+        if (__any(qi < na && cnt[tt] == 3)) {
+            const bool mine = qi < na && cnt[tt] == 3;
+            const double* const aq = A + 33 * (size_t)(qi < na ? qi : 0);
+            double a2n[FM_STEPS];   // (operands one tile ahead, as in the first sweep: nine dependent reads per tile were 0.7 ms for ONE such wave)
+#pragma unroll
+            for (int st = 0; st < FM_STEPS; ++st) a2n[st] = (tb >> 4) < t_end ? opt[((size_t)(tb >> 4) * FM_STEPS + st) * 64 + lane] : 0.0;
+            for (int t = tb >> 4; t < t_end; ++t) {
+                double a2[FM_STEPS];
+#pragma unroll
+                for (int st = 0; st < FM_STEPS; ++st) a2[st] = a2n[st];
+                if (t + 1 < t_end) {
+#pragma unroll
+                    for (int st = 0; st < FM_STEPS; ++st) a2n[st] = opt[((size_t)(t + 1) * FM_STEPS + st) * 64 + lane];
+                }
+                fm_v4 acc2 = fm_v4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int st = 0; st < FM_STEPS; ++st) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[st], bq[tt][st], acc2, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = t * 16 + (lane >> 4) + 4 * r;
+                    if (mine && j < te && acc2[r] <= m[tt] + tau[tt]) {
+                        const double d = fm_exact(aq, B + 33 * (size_t)j);
+                        if (d < best) { best = d; bj = j; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            const double od = __shfl_xor(best, off, 64);
+            const int oj = __shfl_xor(bj, off, 64);
+            if (oj >= 0 && (bj < 0 || od < best || (od == best && oj < bj))) { best = od; bj = oj; }
+        }
+        if (qi < na && (lane >> 4) == 0) { idx_out[(long long)blockIdx.y * na + qi] = bj; d2_out[(long long)blockIdx.y * na + qi] = best; }
+    }
+}
 
 __global__ void __launch_bounds__(256) feature_match_jobs_kernel(const init_job* __restrict__ jobs, int mutual) {
     __shared__ double tile[FM_TILE * 33];
@@ -787,12 +1068,12 @@ __global__ void __launch_bounds__(256) feature_match_jobs_kernel(const init_job*
     if ((long long)blockIdx.x * 256 >= na) return;   // (the whole block)
     feature_match_body<33>(back ? J.fb : J.fa, na, back ? J.fa : J.fb, nb, 33, job_per(nb), back ? J.ci_ba : J.ci_ab, back ? J.cd_ba : J.cd_ab, blockIdx.x, blockIdx.y, tile);
 }
-__global__ void __launch_bounds__(256) feature_match_merge_jobs_kernel(const init_job* __restrict__ jobs, int mutual) {
+__global__ void __launch_bounds__(256) feature_match_merge_jobs_kernel(const init_job* __restrict__ jobs, int mutual, int splits) {
     const init_job J = jobs[blockIdx.y >> 1];
     const bool back = (blockIdx.y & 1) != 0;
     if (back && !mutual) return;
     const long long na = back ? J.nb : J.na;
-    feature_match_merge_body(back ? J.ci_ba : J.ci_ab, back ? J.cd_ba : J.cd_ab, na, JOB_SPLITS, back ? J.ji : J.ij, back ? J.dba : J.dab, blockIdx.x);
+    feature_match_merge_body(back ? J.ci_ba : J.ci_ab, back ? J.cd_ba : J.cd_ab, na, splits, back ? J.ji : J.ij, back ? J.dba : J.dab, blockIdx.x);
 }
 __global__ void __launch_bounds__(256) corr_build_jobs_kernel(const init_job* __restrict__ jobs, int mutual, int min_mutual, int max_iteration) {
     __shared__ corr_lds s_L;
@@ -831,9 +1112,6 @@ int* fail_word(pcr_ctx* ctx) { return (int*)(ctx->d_counters + 116); }
 // A cloud of a few thousand points (what the 2 m down-sample of main.py:35 leaves of a scan: 300 - 1 500 points) is searched without
 // an index: two grid builds per scan -- one per radius, ~20 launches each -- cost several times what the neighbourhoods themselves
 // cost, and a wave reads 4 096 records in 64 trips.  The "view" of such a cloud: its records in row order, levels = 0.
-#ifndef PCR_HYBRID_BRUTE_MAX
-#define PCR_HYBRID_BRUTE_MAX 4096
-#endif
 bool brute_view(const pcr_cloud* cloud, pcr_grid_view* v) {
     static const bool off = getenv("PCR_HYBRID_GRID") != nullptr;   // A/B: always build the grid
     if (off || cloud->n > PCR_HYBRID_BRUTE_MAX || cloud->morton_sorted) return false;
@@ -1083,6 +1361,12 @@ struct scan_chunk {
     int64_t ng = 0;
     int n_scans = 0;
     std::vector<unsigned int> first;   // host copy of scan_first
+    // matrix-core operands of the descriptors (feature_match_mfma_jobs_kernel): per scan ceil(n / 16) tiles from tile_first[scan]
+    double *op_t = nullptr, *op_q = nullptr, *norm2 = nullptr;
+    unsigned long long* max_norm2 = nullptr;
+    unsigned int* min_row = nullptr;
+    std::vector<unsigned int> tile_first;
+    size_t tiles = 0;
 };
 struct scan_slot { int chunk = -1, local = 0; };
 
@@ -1116,6 +1400,7 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
         fprintf(stderr, "pcr_global_init_batch: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    const bool use_mfma = getenv("PCR_INIT_MATCH_VALU") == nullptr;   // A/B and tests: the matching of the pair stage on the vector ALUs (read per call)
     constexpr int64_t CHUNK_PTS = 16ll << 20;
     constexpr int CHUNK_SCANS = 2048;
     std::vector<scan_slot> slot((size_t)n_clouds);
@@ -1127,6 +1412,11 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
             if (c.vsid) pcr_dev_free(ctx, c.vsid, 4 * (size_t)(c.ng > 0 ? c.ng : 1));
             if (c.scan_first) pcr_dev_free(ctx, c.scan_first, 4 * (size_t)(c.n_scans + 1));
             if (c.fpfh) pcr_dev_free(ctx, c.fpfh, sizeof(double) * 33 * (size_t)(c.ng > 0 ? c.ng : 1));
+            if (c.op_t) pcr_dev_free(ctx, c.op_t, 8 * 64 * (size_t)FM_STEPS * (c.tiles ? c.tiles : 1));
+            if (c.op_q) pcr_dev_free(ctx, c.op_q, 8 * 64 * (size_t)FM_STEPS * (c.tiles ? c.tiles : 1));
+            if (c.norm2) pcr_dev_free(ctx, c.norm2, 8 * (size_t)(c.ng > 0 ? c.ng : 1));
+            if (c.max_norm2) pcr_dev_free(ctx, c.max_norm2, 8 * (size_t)(c.n_scans + 1));
+            if (c.min_row) pcr_dev_free(ctx, c.min_row, 4 * (size_t)(c.n_scans + 1));
         }
         chunks.clear();
     };
@@ -1274,6 +1564,29 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
         else
             hipLaunchKernelGGL(fpfh_scans_kernel<NB_CAP>, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_max_nn, (const double*)b_spfh.as<double>(),
                                (const unsigned int*)b_id.as<unsigned int>(), (const double*)b_d2.as<double>(), (const int*)b_cnt.as<int>(), c.fpfh);
+        if (use_mfma) {
+            c.tile_first.assign((size_t)c.n_scans + 1, 0u);
+            for (int k = 0; k < c.n_scans; ++k) c.tile_first[(size_t)k + 1] = c.tile_first[(size_t)k] + (c.first[(size_t)k + 1] - c.first[(size_t)k] + 15u) / 16u;
+            c.tiles = c.tile_first[(size_t)c.n_scans];
+            pcr_dev_block b_tf(ctx), b_dup(ctx);
+            if ((rc = b_dup.alloc(ng ? ng : 1))) break;
+            const size_t op_bytes = 8 * 64 * (size_t)FM_STEPS * (c.tiles ? c.tiles : 1);
+            if ((rc = pcr_dev_alloc(ctx, op_bytes, (void**)&c.op_t)) || (rc = pcr_dev_alloc(ctx, op_bytes, (void**)&c.op_q)) || (rc = pcr_dev_alloc(ctx, 8 * (ng ? ng : 1), (void**)&c.norm2)) ||
+                (rc = pcr_dev_alloc(ctx, 8 * (size_t)(c.n_scans + 1), (void**)&c.max_norm2)) || (rc = pcr_dev_alloc(ctx, 4 * (size_t)(c.n_scans + 1), (void**)&c.min_row)) ||
+                (rc = b_tf.alloc(4 * (size_t)(c.n_scans + 1))))
+                break;
+            if (hipMemcpyAsync(b_tf.p, c.tile_first.data(), 4 * (size_t)(c.n_scans + 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipMemsetAsync(c.max_norm2, 0, 8 * (size_t)(c.n_scans + 1), ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
+            hipLaunchKernelGGL(dup_rows_kernel, dim3((unsigned)c.n_scans), dim3(1024), 0, ctx->stream, (const double*)c.fpfh, (const unsigned int*)c.scan_first, b_dup.as<unsigned char>());
+            if (c.tiles)
+                hipLaunchKernelGGL(mfma_ops_kernel, dim3((unsigned)c.tiles), dim3(64), 0, ctx->stream, (const double*)c.fpfh, (const unsigned int*)c.scan_first, c.n_scans,
+                                   (const unsigned int*)b_tf.as<unsigned int>(), (const unsigned char*)b_dup.as<unsigned char>(), c.op_t, c.op_q, c.norm2, c.max_norm2);
+            hipLaunchKernelGGL(min_norm_row_kernel, dim3((unsigned)c.n_scans), dim3(256), 0, ctx->stream, (const double*)c.norm2, (const unsigned int*)c.scan_first, c.min_row);
+            if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
+            rc = read_fail(ctx);   // (synchronises: the chunk's scratch -- and the tile table -- and the pinned block are free for the next chunk)
+            lap("normals + SPFH + FPFH");
+            continue;
+        }
         if (hipGetLastError() != hipSuccess) { rc = PCR_E_HIP; break; }
         rc = read_fail(ctx);   // (synchronises: the chunk's scratch and the pinned block are free for the next chunk)
         lap("normals + SPFH + FPFH");
@@ -1301,6 +1614,11 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
             if (J.na <= 0 || J.nb <= 0) continue;
             J.src = cs.down + fs; J.tgt = ct.down + ft;
             J.fa = cs.fpfh + 33 * (size_t)fs; J.fb = ct.fpfh + 33 * (size_t)ft;
+            if (use_mfma) {
+                const size_t ts = (size_t)cs.tile_first[(size_t)S.local] * FM_STEPS * 64, tt = (size_t)ct.tile_first[(size_t)T.local] * FM_STEPS * 64;
+                J.ta = cs.op_t + ts; J.qa = cs.op_q + ts; J.n2a = cs.norm2 + fs; J.mxa = (const double*)(cs.max_norm2 + S.local); J.mra = cs.min_row + S.local;
+                J.tb = ct.op_t + tt; J.qb = ct.op_q + tt; J.n2b = ct.norm2 + ft; J.mxb = (const double*)(ct.max_norm2 + T.local); J.mrb = ct.min_row + T.local;
+            }
             J.seed = g->ransac.seed;
             // pool offsets (resolved below): ij na | ji nb | ci_ab S*na | ci_ba S*nb | corr 2 na + 4 | inl BATCH   (ints)
             //                                dab na | dba nb | cd_ab S*na | cd_ba S*nb | err2 BATCH | Tout 12 BATCH | state   (doubles)
@@ -1340,8 +1658,11 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
         if (hipMemcpyAsync(b_jobs.p, jobs.data(), sizeof(init_job) * nj, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
         const init_job* d_jobs = b_jobs.as<const init_job>();
         const unsigned qb = (unsigned)((max_n + 255) / 256);
-        hipLaunchKernelGGL(feature_match_jobs_kernel, dim3(qb, JOB_SPLITS, 2 * nj), dim3(256), 0, ctx->stream, d_jobs, mutual);
-        hipLaunchKernelGGL(feature_match_merge_jobs_kernel, dim3(qb, 2 * nj), dim3(256), 0, ctx->stream, d_jobs, mutual);
+        // (matrix-core sweep: one split -- 4 waves per 256 queries and direction -- unless a pair or two are all there is)
+        const int mfma_splits = (long long)nj * 2 * qb * 4 >= (long long)ctx->cu_count ? 1 : (JOB_SPLITS < 4 ? JOB_SPLITS : 4);
+        if (use_mfma) hipLaunchKernelGGL(feature_match_mfma_jobs_kernel, dim3(qb, mfma_splits, 2 * nj), dim3(256), 0, ctx->stream, d_jobs, mutual, mfma_splits);
+        else hipLaunchKernelGGL(feature_match_jobs_kernel, dim3(qb, JOB_SPLITS, 2 * nj), dim3(256), 0, ctx->stream, d_jobs, mutual);
+        hipLaunchKernelGGL(feature_match_merge_jobs_kernel, dim3(qb, 2 * nj), dim3(256), 0, ctx->stream, d_jobs, mutual, use_mfma ? mfma_splits : JOB_SPLITS);
         hipLaunchKernelGGL(corr_build_jobs_kernel, dim3(nj), dim3(256), 0, ctx->stream, d_jobs, mutual, 9, g->ransac.max_iteration);
         lap("matching + correspondences");
         ransac_common rcmn;
