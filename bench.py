@@ -473,7 +473,8 @@ def global_init_leg(pkg, ctx, src, tgt, dev_id, streams, with_batch=True):
         rows[tag] = {"seconds": min(runs), "pairs_per_s": P / min(runs), "runs_s": runs, "mean_iters": float(np.mean([x["iters"] for x in r]))}
     rows["global_init_ms_per_pair"] = 1e3 * (rows["with_global_init"]["seconds"] - rows["icp_only"]["seconds"]) / P
     rows["pairs"], rows["points_per_cloud"], rows["streams_per_gpu"] = P, BATCH_POINTS, streams
-    rows["entry_point"] = "register_batch(pairs, global_init=True) -> pcr_register_pairs: every scan preprocessed once per call, one pcr_global_registration per pair, T0 into the fused ICP batch"
+    rows["entry_point"] = ("register_batch(pairs, global_init=True) -> pcr_register_pairs: the initialisation fused for the whole share (every scan down-sampled by one sort, "
+                           "normals / SPFH / FPFH one launch each, matching on the f64 matrix cores and the RANSAC loop for all pairs side by side), T0 into the fused ICP batch")
     out["batch256"] = rows
     return out
 
