@@ -202,14 +202,31 @@ __device__ static void smallest_eigvec(const double S[6], double n[3]) {
 
 // ------------------------------------------------------------ hybrid normals
 // returns false when the point has to be done again with the full candidate array
+// the normal of a point from the covariance S of its neighbourhood (cnt < 3: Open3D's (0, 0, 1)); the same arithmetic whoever runs it
+__device__ static inline void normal_from_cov(const double S[6], int cnt, const pcr_pt& p, int orient, double vx, double vy, double vz, double nrm[3]) {
+    nrm[0] = 0.0; nrm[1] = 0.0; nrm[2] = 1.0;
+    if (cnt < 3) return;
+    smallest_eigvec(S, nrm);
+    const double len = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    if (len == 0.0 || !(len == len)) { nrm[0] = 0; nrm[1] = 0; nrm[2] = 1; }
+    else if (orient) {
+        const double d = nrm[0] * (vx - p.x) + nrm[1] * (vy - p.y) + nrm[2] * (vz - p.z);
+        if (d < 0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+    }
+}
+// `cov` (or null): the covariance and the count go to cov[7 * row .. + 7) and the normal is left to normals_finish_kernel -- one THREAD
+// per point there: the Jacobi sweeps are ~1 000 dependent instructions, 40 % of this kernel's when a whole wave runs them for one point
 template <int CAP>
 __device__ static bool normals_body(const pcr_grid_view& gv, const pcr_pt& p, double r2, int max_nn, int orient, double vx, double vy, double vz,
-                                    double* __restrict__ normals /* (n,3) by row */, int* __restrict__ fail, hybrid_lds_t<CAP>* L) {
+                                    double* __restrict__ normals /* (n,3) by row */, int* __restrict__ fail, hybrid_lds_t<CAP>* L, double* __restrict__ cov = nullptr) {
     nb_entry* const nb = L->nb;
     const int cnt = gather_hybrid<CAP>(gv, p.x, p.y, p.z, r2, max_nn, L);
     if (cnt == -2) return false;
-    if (cnt < 0) { if (threadIdx.x == 0) atomicAdd(fail, 1); return true; }
-    double nrm[3] = {0.0, 0.0, 1.0};  // Open3D's value for neighbourhoods of fewer than 3 points
+    if (cnt < 0) {
+        if (threadIdx.x == 0) { atomicAdd(fail, 1); if (cov) cov[7 * p.id + 6] = 0.0; }
+        return true;
+    }
+    double S[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (cnt >= 3) {
         // cumulants about the query point (Open3D accumulates raw coordinates; centring first is the same
         // covariance with less cancellation)
@@ -222,15 +239,18 @@ __device__ static bool normals_body(const pcr_grid_view& gv, const pcr_pt& p, do
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) c[k] = wave_sum(c[k]) / (double)cnt;
-        const double S[6] = {c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2], c[6] - c[1] * c[1], c[7] - c[1] * c[2], c[8] - c[2] * c[2]};
-        smallest_eigvec(S, nrm);
-        const double len = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-        if (len == 0.0 || !(len == len)) { nrm[0] = 0; nrm[1] = 0; nrm[2] = 1; }
-        else if (orient) {
-            const double d = nrm[0] * (vx - p.x) + nrm[1] * (vy - p.y) + nrm[2] * (vz - p.z);
-            if (d < 0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
-        }
+        S[0] = c[3] - c[0] * c[0]; S[1] = c[4] - c[0] * c[1]; S[2] = c[5] - c[0] * c[2];
+        S[3] = c[6] - c[1] * c[1]; S[4] = c[7] - c[1] * c[2]; S[5] = c[8] - c[2] * c[2];
     }
+    if (cov) {
+        if (threadIdx.x < 7) {
+            const double v = threadIdx.x == 0 ? S[0] : threadIdx.x == 1 ? S[1] : threadIdx.x == 2 ? S[2] : threadIdx.x == 3 ? S[3] : threadIdx.x == 4 ? S[4] : threadIdx.x == 5 ? S[5] : (double)cnt;
+            cov[7 * p.id + threadIdx.x] = v;
+        }
+        return true;
+    }
+    double nrm[3];
+    normal_from_cov(S, cnt, p, orient, vx, vy, vz, nrm);
     const double n0 = nrm[0], n1 = nrm[1], n2 = nrm[2];
     if (threadIdx.x < 3) normals[3 * p.id + threadIdx.x] = threadIdx.x == 0 ? n0 : (threadIdx.x == 1 ? n1 : n2);
     return true;
@@ -267,7 +287,7 @@ __device__ static inline unsigned int scans_block_view(const scans_view& V, long
 template <int CAP>
 __global__ void __launch_bounds__(64) normals_scans_kernel(scans_view V, long long ng, double r2, int max_nn, double* __restrict__ normals /* (ng,3) */, int* __restrict__ fail,
                                                            const unsigned int* __restrict__ todo, const unsigned int* __restrict__ todo_count, unsigned int* __restrict__ redo,
-                                                           unsigned int* __restrict__ redo_count) {
+                                                           unsigned int* __restrict__ redo_count, double* __restrict__ cov /* (ng,7): covariance + count; the normals follow in normals_finish_kernel */) {
     __shared__ hybrid_lds_t<CAP> s_L;
     const long long n_do = todo ? (long long)*todo_count : ng;
     for (long long t = blockIdx.x; t < n_do; t += gridDim.x) {
@@ -275,10 +295,21 @@ __global__ void __launch_bounds__(64) normals_scans_kernel(scans_view V, long lo
         pcr_grid_view gv;
         const unsigned int base = scans_block_view(V, i, &gv);
         const pcr_pt p = V.down[i];
-        const bool done = normals_body<CAP>(gv, p, r2, max_nn, 1, 0.0, 0.0, 0.0, normals + 3 * (size_t)base, fail, &s_L);
+        const bool done = normals_body<CAP>(gv, p, r2, max_nn, 1, 0.0, 0.0, 0.0, normals + 3 * (size_t)base, fail, &s_L, cov + 7 * (size_t)base);
         if (!done && threadIdx.x == 0) redo[atomicAdd(redo_count, 1u)] = (unsigned int)i;
         __syncthreads();   // (the candidate array is reused by the next point)
     }
+}
+// one thread per down-sampled point of the chunk: covariance -> normal (towards the origin, as pcr_preprocess asks)
+__global__ void __launch_bounds__(256) normals_finish_kernel(scans_view V, long long ng, const double* __restrict__ cov, double* __restrict__ normals) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ng) return;
+    const pcr_pt p = V.down[i];   // (record base + r is row r: cov and normals of point i sit at i)
+    double S[6], nrm[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S[k] = cov[7 * i + k];
+    normal_from_cov(S, (int)cov[7 * i + 6], p, 1, 0.0, 0.0, 0.0, nrm);
+    normals[3 * i] = nrm[0]; normals[3 * i + 1] = nrm[1]; normals[3 * i + 2] = nrm[2];
 }
 
 // ---------------------------------------------------------------------- SPFH
@@ -1540,17 +1571,18 @@ int pcr_global_init_batch(pcr_ctx* ctx, const pcr_cloud_ref* clouds, int64_t n_c
             (rc = b_id.alloc(sizeof(unsigned int) * (size_t)g->fpfh_max_nn * ng)) || (rc = b_d2.alloc(sizeof(double) * (size_t)g->fpfh_max_nn * ng)) || (rc = b_cnt.alloc(sizeof(int) * ng)))
             break;
         const scans_view V{c.down, c.vsid, c.scan_first};
-        pcr_dev_block b_redo(ctx);
-        if ((rc = b_redo.alloc(4 * ng))) break;
+        pcr_dev_block b_redo(ctx), b_cov(ctx);
+        if ((rc = b_redo.alloc(4 * ng)) || (rc = b_cov.alloc(sizeof(double) * 7 * ng))) break;
         unsigned int* const redo = b_redo.as<unsigned int>();
         unsigned int* const redo_n = ctx->d_counters + 117;   // [0]: normals, [1]: SPFH (zero between calls)
         const unsigned fixed = (unsigned)(ng < (size_t)(16 * ctx->cu_count) ? ng : (size_t)(16 * ctx->cu_count));
         const unsigned int* const none = nullptr;
         if (hipMemsetAsync(redo_n, 0, 8, ctx->stream) != hipSuccess) { rc = PCR_E_HIP; break; }
         hipLaunchKernelGGL(normals_scans_kernel<128>, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->normal_radius * g->normal_radius, g->normal_max_nn,
-                           b_nrm.as<double>(), fail_word(ctx), none, none, redo, redo_n);
+                           b_nrm.as<double>(), fail_word(ctx), none, none, redo, redo_n, b_cov.as<double>());
         hipLaunchKernelGGL(normals_scans_kernel<NB_CAP>, dim3(fixed), dim3(64), 0, ctx->stream, V, (long long)ng, g->normal_radius * g->normal_radius, g->normal_max_nn,
-                           b_nrm.as<double>(), fail_word(ctx), (const unsigned int*)redo, (const unsigned int*)redo_n, (unsigned int*)nullptr, (unsigned int*)nullptr);
+                           b_nrm.as<double>(), fail_word(ctx), (const unsigned int*)redo, (const unsigned int*)redo_n, (unsigned int*)nullptr, (unsigned int*)nullptr, b_cov.as<double>());
+        hipLaunchKernelGGL(normals_finish_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, ctx->stream, V, (long long)ng, (const double*)b_cov.as<double>(), b_nrm.as<double>());
         // (the SPFH list is written behind the normals' one: both launches of a stage are done before the next stage's first)
         hipLaunchKernelGGL(spfh_scans_kernel<256>, dim3((unsigned)ng), dim3(64), 0, ctx->stream, V, (long long)ng, g->fpfh_radius * g->fpfh_radius, g->fpfh_max_nn,
                            (const double*)b_nrm.as<double>(), b_spfh.as<double>(), b_id.as<unsigned int>(), b_d2.as<double>(), b_cnt.as<int>(), fail_word(ctx), none, none, redo,
