@@ -207,9 +207,17 @@ def coarse_to_fine_icp(src_cloud, tgt_cloud, leaves=(1.0, 0.4, 0.0), *, init=Non
     src_full = DeviceCloud.upload(points_of(src_cloud), ctx)
     tgt_full = DeviceCloud.upload(points_of(tgt_cloud), ctx)
     logs = []
+    leaves = tuple(leaves)
+    src_alive = True
     try:
-        for leaf in leaves:
-            s = voxel_filter_device(src_full, leaf) if leaf > 0 else DeviceCloud.upload(src_full.download(), ctx)
+        for k, leaf in enumerate(leaves):
+            if leaf > 0:
+                s = voxel_filter_device(src_full, leaf)
+            elif k == len(leaves) - 1:
+                s = src_full            # the last level registers the full cloud itself (ICP moves its source in place: nobody needs it afterwards);
+                src_alive = False       # a copy through the host was 2-3 ms of a 10-ms refinement at 1 M points
+            else:
+                s = DeviceCloud.upload(src_full.download(), ctx)
             t = voxel_filter_device(tgt_full, leaf) if leaf > 0 else tgt_full
             index = TargetIndex(t, ctx=ctx)
             try:
@@ -223,7 +231,8 @@ def coarse_to_fine_icp(src_cloud, tgt_cloud, leaves=(1.0, 0.4, 0.0), *, init=Non
             T = res["T"]
             logs.append({"leaf": leaf, "iters": res["iters"], "n_assoc": res["n_assoc"], "mean_d2": res["mean_d2"]})
     finally:
-        src_full.free()
+        if src_alive:
+            src_full.free()
         tgt_full.free()
     return T, logs
 
