@@ -506,6 +506,7 @@ def config5_leg(pkg, ctx):
     src = (world - T_off[:3, 3]) @ T_off[:3, :3]
     src = src + np.random.default_rng(7).normal(0, 0.01, src.shape)
     c2f_runs = []
+    pkg.coarse_to_fine_icp(src, world, leaves=(2.0, 0.5, 0.0), max_iteration=30)   # untimed: the first 1 M-point run of a process grows the arena and the staging blocks
     for _ in range(3):   # median of three (a single call can be hit by the platform's 30-50 ms stalls: DESIGN section 3.1.7); all three listed
         t0 = time.perf_counter()
         T, logs = pkg.coarse_to_fine_icp(src, world, leaves=(2.0, 0.5, 0.0), max_iteration=30)
